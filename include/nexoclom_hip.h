@@ -1,0 +1,182 @@
+/* nexoclom_hip.h -- C ABI of libnexoclom_hip.so: nexoclom's particle_tracking + image hot path
+ * on AMD MI355X (gfx950).
+ *
+ * The reference (mburger-stsci/nexoclom, pure Python/NumPy) has no FFI on this path; its "plugin
+ * boundary" is a set of plain Python call sites.  Each entry point below replaces one of them and
+ * is what a ctypes binding inside the reference would call (INTEGRATION.md shows the stubs).
+ * Citations are paths under the reference tree's nexoclom/ directory.
+ *
+ *   nxc_state              state(x, output)                       particle_tracking/state.py:17-74
+ *   nxc_rk5_step           rk5(output, X0, h)                     particle_tracking/rk5.py:21-54
+ *   nxc_integrate_const    Output.constant_step_size_driver()     particle_tracking/Output.py:368-455
+ *                          (+ optionally fused ModelImage.create_image of every stored step)
+ *   nxc_integrate_var      Output.variable_step_size_driver()     particle_tracking/Output.py:221-366
+ *   nxc_image_accumulate   ModelImage.create_image()              data_simulation/ModelImage.py:229-274
+ *                          + ModelResult.packet_weighting()       data_simulation/ModelResult.py:140-170
+ *                          + Histogram2d()                        math/histogram.py:28-39
+ *   nxc_image_allreduce    the per-output-file image sum          data_simulation/ModelImage.py:96-98
+ *
+ * Conventions
+ *   - Every function returns 0 on success or a negative nxc_status; nothing is thrown across the
+ *     boundary.  nxc_last_error_string() describes the last failure on the calling thread.
+ *   - All array arguments are caller-owned HOST buffers, C-contiguous, fp64 unless stated; no
+ *     pointer is retained after the call returns, except the table pointers inside nxc_forces /
+ *     nxc_image_desc, which are copied to the device during nxc_set_forces / nxc_set_image.
+ *   - Packet arrays are struct-of-arrays: soa[c*n + i], column c = 0..7 =
+ *     t_remaining, x, y, z, vx, vy, vz, frac (the reference's (N,8) row layout, transposed);
+ *     lengths in planet radii, times in seconds.
+ *   - A handle owns one device, one HIP stream, its tables, a resident packet set and a resident
+ *     image pair.  One host thread per handle; calls are synchronous unless named *_async.
+ *   - The reference's asserts (Output.py:254,284,287,388-389; rk5.py:52) become counters
+ *     (nxc_counters) that the Python shim turns back into AssertionError.
+ */
+#ifndef NEXOCLOM_HIP_H
+#define NEXOCLOM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NXC_ABI_VERSION 1
+#define NXC_MAX_LINES 4
+
+typedef enum {
+    NXC_OK = 0,
+    NXC_ERR_HIP = -1,        /* a HIP runtime call failed (message has the HIP error)   */
+    NXC_ERR_ARG = -2,        /* invalid argument / missing prerequisite call            */
+    NXC_ERR_NO_DEVICE = -3,  /* no gfx950-class device visible                          */
+    NXC_ERR_RCCL = -4,       /* librccl missing or a collective failed                  */
+    NXC_ERR_STATE = -5       /* handle not in the state the call needs                  */
+} nxc_status;
+
+/* Scalars and table consumed by state() (what Output.__init__ hangs on `output`,
+ * particle_tracking/Output.py:105-128). */
+typedef struct nxc_forces {
+    double GM;          /* R^3/s^2; NEGATIVE as in the reference (solarsystem/SSObject.py:53)    */
+    double vrplanet;    /* R/s, radial velocity of the planet w.r.t. the Sun                     */
+    double photo;       /* 1/s, loss_info.photo (state.py:48-52); used when has_photo            */
+    double lifetime;    /* s; > 0 selects the constant loss rate 1/lifetime (state.py:44-46)     */
+    int32_t gravity;    /* inputs.forces.gravity                                                 */
+    int32_t radpres;    /* inputs.forces.radpres                                                 */
+    int32_t has_photo;  /* loss_info.photo is not None                                           */
+    int32_t reserved;
+    int64_t n_tab;      /* radiation-acceleration table length (>= 2)                            */
+    const double *v_tab;/* R/s, strictly ascending  (radpres.velocity)                           */
+    const double *a_tab;/* R/s^2                    (radpres.accel)                              */
+} nxc_forces;
+
+/* Everything create_image needs besides the packets (ModelImage.py:53-78,229-269). */
+typedef struct nxc_image_desc {
+    double M[9];          /* row-major sun->observer rotation (ModelImage.image_rotation)        */
+    double vrplanet;      /* R/s, added to vy for the g-value lookup (ModelImage.py:242-243)     */
+    double apix_cm2;      /* pixel area in cm^2; weights are divided by it (ModelImage.py:262)   */
+    int32_t quantity;     /* 0 = column/density (w = frac), 1 = radiance/difrad                  */
+    int32_t n_lines;      /* number of g-value tables summed for radiance (<= NXC_MAX_LINES)     */
+    int32_t downcast_f32; /* 1: round x,y,z,vy,frac through float32 first, as the reference's
+                             save()/restore() pair does (Output.py:528-543,555-570)              */
+    int32_t reserved;
+    int64_t nx, nz;       /* image dims (bins along x_obs, z_obs)                                */
+    const double *xedges; /* nx+1 bin edges = np.linspace(lo, hi, nx+1)                          */
+    const double *zedges; /* nz+1 bin edges                                                      */
+    int64_t line_n[NXC_MAX_LINES];
+    const double *line_v[NXC_MAX_LINES]; /* R/s ascending (gValue.velocity converted)            */
+    const double *line_g[NXC_MAX_LINES]; /* 1/s           (gValue.g)                             */
+} nxc_image_desc;
+
+/* Work and assertion counters of the last integrate / image call on the handle. */
+typedef struct nxc_counters {
+    uint64_t particle_steps; /* rk5 steps taken = sum over iterations of active packets          */
+    uint64_t samples;        /* packet samples offered to the image (frac > 0 records)           */
+    uint64_t samples_binned; /* of those, inside the image range                                 */
+    uint64_t nonfinite;      /* non-finite state / errmax / weight events                        */
+    uint64_t bad_step;       /* step size <= 0 or not finite (variable driver)                   */
+    uint64_t neg_frac;       /* accepted step with frac < 0 (variable driver, Output.py:287)     */
+    uint64_t unfinished;     /* packets stopped by max_steps before reaching their end time      */
+    uint64_t reserved;
+} nxc_counters;
+
+typedef struct nxc_handle nxc_handle;
+
+/* ---- device / library ------------------------------------------------------------------------ */
+int nxc_abi_version(void);
+int nxc_device_count(int *count);
+const char *nxc_last_error_string(void);
+int nxc_create(int device, nxc_handle **out);
+int nxc_destroy(nxc_handle *h);
+int nxc_device_name(nxc_handle *h, char *buf, int buflen);
+int nxc_synchronize(nxc_handle *h);
+
+/* ---- set-up ---------------------------------------------------------------------------------- */
+int nxc_set_forces(nxc_handle *h, const nxc_forces *f);
+int nxc_set_image(nxc_handle *h, const nxc_image_desc *d);   /* also zeroes the resident image    */
+
+/* ---- a-2: state() ---------------------------------------------------------------------------- */
+int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const double *z,
+              const double *vy, double *ax, double *ay, double *az, double *ioniz);
+
+/* ---- a-1: rk5() -- one Dormand-Prince step, per-packet step size h[n] -------------------------
+ * soa_out receives the 5th-order state; delta_out (nullable, [8][n]) the reference's
+ * |h * sum_{i<6} (b5-b4)_i k_i| error estimate (rk5.py:38-46). */
+int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *hstep,
+                 double *soa_out, double *delta_out);
+
+/* ---- resident packets / image (what a long run keeps in HBM) ----------------------------------- */
+int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0);
+int nxc_image_clear(nxc_handle *h);
+int nxc_image_download(nxc_handle *h, double *image /* nx*nz */, uint64_t *counts /* nx*nz */);
+int nxc_counters_get(nxc_handle *h, nxc_counters *out);
+int nxc_last_kernel_ms(nxc_handle *h, float *ms);  /* HIP-event time of the last integrate/image launch */
+
+/* ---- a-3 (+ fused a-6..a-8): constant-step driver over the resident packets --------------------
+ * Runs n_iter iterations of {rk5(step); impact r<1; escape r>outeredge; vanish frac<1e-10}
+ * (Output.py:384-431) for every packet until it dies.
+ *   flags & NXC_RUN_IMAGE : every stored record with frac > 0 -- the initial state and the state
+ *                           after each iteration -- is binned into the resident image with the
+ *                           nxc_set_image description (compress=True rule, Output.py:523-524).
+ *   traj_out (nullable)   : host [8][nrec][n]; record 0 = initial state, record k = state after
+ *                           iteration k, zeros once dead (the reference's `results`, transposed).
+ *                           nrec must be >= n_iter+1 when given.
+ *   final_out (nullable)  : host [8][n], state at the packet's last processed iteration.
+ *   steps_out (nullable)  : host int64[n], iterations the packet was active.
+ * With traj_out == NULL the kernel is the persistent lane-refill integrator (no trajectory is
+ * ever materialised); with traj_out it is the lock-step kernel that streams records to HBM. */
+#define NXC_RUN_IMAGE 1u
+int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                        uint32_t flags, double *traj_out, int64_t nrec, double *final_out,
+                        int64_t *steps_out);
+/* Same launch without any host transfer or synchronisation (bench / pipelining). */
+int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                              uint32_t flags);
+
+/* ---- a-4: variable-step driver over the resident packets ---------------------------------------
+ * final_out host [8][n]; hstore_out (nullable) host [n] = stored step_size column at exit. */
+int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,
+                      double *final_out, double *hstore_out);
+
+/* ---- a-6..a-8: image of p stored samples -------------------------------------------------------
+ * Adds to the resident image pair (use nxc_image_clear / nxc_image_download around it). */
+int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
+                         const double *z, const double *vy, const double *frac);
+
+/* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
+ * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other
+ * ranks (any side channel); every rank then calls nxc_comm_init.  nxc_image_allreduce sums the
+ * resident image (fp64) and counts (uint64) over all ranks in place. */
+#define NXC_UNIQUE_ID_BYTES 128
+int nxc_comm_unique_id(uint8_t id[NXC_UNIQUE_ID_BYTES]);
+int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank, int nranks);
+int nxc_comm_destroy(nxc_handle *h);
+int nxc_image_allreduce(nxc_handle *h);
+int nxc_allreduce_max_f64(nxc_handle *h, double *value);   /* control plane: max-over-ranks timer */
+int nxc_barrier(nxc_handle *h);
+
+/* ---- diagnostics used by the parity tests -------------------------------------------------------
+ * which: 0 = exp, 1 = log, 2 = cube (r^3), 3 = sqrt, 4 = x/y with y = in2 (in2 nullable otherwise) */
+int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const double *in2,
+                   double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,55 @@
+"""Build libnexoclom_hip.so (gfx950) in-tree with hipcc.
+
+``python -m nexoclom_amd.build`` or ``nexoclom_amd.build.build()``.  hipcc cross-compiles without a
+GPU; the resulting .so is git-ignored but travels to the GPU box with the snapshot.
+
+Flags that matter for parity: ``-ffp-contract=off -fno-fast-math`` (one rounding per fp64
+operation, as NumPy) and ``-munsafe-fp-atomics`` (hardware global_atomic_add_f64 for the image).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'csrc', 'nxc_api.hip')
+DEPS = [os.path.join(HERE, 'csrc', f) for f in
+        ('nxc_api.hip', 'nxc_kernels.hpp', 'nxc_device.hpp', 'nxc_math.hpp')]
+DEPS.append(os.path.join(os.path.dirname(HERE), 'include', 'nexoclom_hip.h'))
+OUT = os.path.join(HERE, 'lib', 'libnexoclom_hip.so')
+
+FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-fast-math',
+         '-munsafe-fp-atomics', '-fPIC', '-shared', '-std=c++17', '-Wall',
+         '-Wno-unused-function']
+
+
+def hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found; the HIP library cannot be built')
+    return exe
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(d) <= t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc()] + FLAGS + [SRC, '-o', OUT, '-ldl']
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError('hipcc failed building libnexoclom_hip.so')
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

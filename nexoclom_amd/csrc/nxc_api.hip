@@ -1,0 +1,824 @@
+// nxc_api.hip -- C ABI (include/nexoclom_hip.h) over the gfx950 kernels of nxc_kernels.hpp.
+//
+// Host side of the boundary: owns the device, one stream, the packed table blob, the resident
+// packet set and the resident image pair; translates nxc_forces / nxc_image_desc into kernel
+// arguments; never throws across the boundary.  RCCL is loaded lazily with dlopen so that the
+// library loads (and every single-GPU call works) where librccl is absent.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nexoclom_hip.h"
+#include "nxc_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(NXC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+constexpr int BLOCK_PERSIST = NXC_BLOCK;
+
+// ---- RCCL, resolved at first use ------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
+                              ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.ok) return NXC_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return fail(NXC_ERR_RCCL, std::string("dlopen(librccl): ") + dlerror());
+#define SYM(field, name)                                                                     \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, name));        \
+    if (!g_rccl.field) return fail(NXC_ERR_RCCL, std::string("dlsym ") + name + " failed");
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.ok = true;
+    return NXC_OK;
+}
+
+#define NCCLCHK(expr)                                                                        \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail(NXC_ERR_RCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// ---- packed lookup table ----------------------------------------------------------------------
+struct PackedLut {
+    LutDesc desc{};
+    std::vector<unsigned char> bytes;
+};
+
+int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, const char *what)
+{
+    if (n < 2 || n > 65000 || !xp || !fp)
+        return fail(NXC_ERR_ARG, std::string(what) + ": table needs 2..65000 points");
+    for (int64_t j = 0; j + 1 < n; j++)
+        if (!(xp[j + 1] > xp[j]))
+            return fail(NXC_ERR_ARG, std::string(what) + ": abscissae must be strictly ascending");
+    int ncell = 64;
+    while (ncell < 2 * n && ncell < 8192) ncell <<= 1;
+    const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 7) & ~size_t(7);
+    out.bytes.assign((size_t)3 * n * sizeof(double) + cell_bytes, 0);
+    double *base = reinterpret_cast<double *>(out.bytes.data());
+    std::memcpy(base, xp, n * sizeof(double));
+    std::memcpy(base + n, fp, n * sizeof(double));
+    for (int64_t j = 0; j + 1 < n; j++)      // np.interp's slope, same IEEE quotient
+        base[2 * n + j] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+    unsigned short *cell = reinterpret_cast<unsigned short *>(base + 3 * n);
+    const double x0 = xp[0], xl = xp[n - 1];
+    const double inv_w = (double)ncell / (xl - x0);
+    for (int c = 0; c <= ncell; c++) {
+        const double edge = x0 + (double)c / inv_w;
+        int64_t j = std::upper_bound(xp, xp + n, edge) - xp - 1;   // xp[j] <= edge
+        j = std::max<int64_t>(0, j - 1);                           // margin for rounding
+        cell[c] = (unsigned short)j;
+    }
+    out.desc.n = (int)n;
+    out.desc.ncell = ncell;
+    out.desc.x0 = x0;
+    out.desc.xlast = xl;
+    out.desc.inv_w = inv_w;
+    out.desc.offset_bytes = 0;
+    out.desc.size_bytes = (int64_t)out.bytes.size();
+    return NXC_OK;
+}
+
+}  // namespace
+
+struct nxc_handle {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    char name[256] = {0};
+
+    // tables
+    bool have_forces = false, have_image = false;
+    ForceK F{};
+    ImageK G{};
+    PackedLut force_lut;
+    std::vector<unsigned char> image_part;       // lines, then xedges, zedges
+    LutDesc line_local[NXC_MAX_LINES]{};
+    int64_t xedges_local = 0, zedges_local = 0;
+    unsigned char *d_blob = nullptr;
+    size_t blob_cap = 0, force_bytes = 0, all_bytes = 0;
+
+    // resident data
+    double *d_image = nullptr;
+    unsigned long long *d_counts = nullptr;
+    size_t npix = 0;
+    double *d_packets = nullptr;
+    size_t packets_cap = 0;
+    int64_t n_packets = 0;
+    DevCounters *d_ctr = nullptr;
+    double *d_scratch = nullptr;     // final states / generic device scratch
+    size_t scratch_cap = 0;
+    long long *d_steps = nullptr;
+    size_t steps_cap = 0;
+
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    double *d_reduce = nullptr;      // one double for control-plane reductions
+};
+
+namespace {
+
+int ensure(void **ptr, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes && *ptr) return NXC_OK;
+    if (*ptr) HIPCHK(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIPCHK(hipMalloc(ptr, bytes ? bytes : 8));
+    *cap = bytes;
+    return NXC_OK;
+}
+
+int upload_blob(nxc_handle *h)
+{
+    const size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
+    const size_t ib = h->have_image ? h->image_part.size() : 0;
+    h->force_bytes = fb;
+    h->all_bytes = fb + ib;
+    if (h->all_bytes > 160 * 1024)
+        return fail(NXC_ERR_ARG, "lookup tables exceed the 160 KiB LDS of a gfx950 CU");
+    int rc = ensure(reinterpret_cast<void **>(&h->d_blob), &h->blob_cap, h->all_bytes);
+    if (rc) return rc;
+    if (fb) HIPCHK(hipMemcpyAsync(h->d_blob, h->force_lut.bytes.data(), fb, hipMemcpyHostToDevice,
+                                  h->stream));
+    if (ib) HIPCHK(hipMemcpyAsync(h->d_blob + fb, h->image_part.data(), ib, hipMemcpyHostToDevice,
+                                  h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->F.tab = h->force_lut.desc;
+    h->F.tab.offset_bytes = 0;
+    if (h->have_image) {
+        for (int l = 0; l < h->G.n_lines; l++) {
+            h->G.line[l] = h->line_local[l];
+            h->G.line[l].offset_bytes += (int64_t)fb;
+        }
+        h->G.xedges_off = h->xedges_local + (int64_t)fb;
+        h->G.zedges_off = h->zedges_local + (int64_t)fb;
+    }
+    return NXC_OK;
+}
+
+template <class K>
+int prep_kernel(K kernel, size_t lds_bytes)
+{
+    if (lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    return NXC_OK;
+}
+
+template <class K>
+int persistent_grid(nxc_handle *h, K kernel, int block, size_t lds_bytes, int64_t n, int *grid)
+{
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    int64_t g = (int64_t)h->n_cu * per_cu;
+    const int64_t need = (n + block - 1) / block;
+    if (g > need) g = need;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return NXC_OK;
+}
+
+int flat_grid(nxc_handle *h, int64_t n, int block)
+{
+    int64_t g = (n + block - 1) / block;
+    const int64_t cap = (int64_t)h->n_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int begin_timed(nxc_handle *h)
+{
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return NXC_OK;
+}
+int end_timed(nxc_handle *h)
+{
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return NXC_OK;
+}
+
+int need_forces(nxc_handle *h)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    if (!h->have_forces) return fail(NXC_ERR_STATE, "nxc_set_forces has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    return NXC_OK;
+}
+
+int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, bool image,
+                 double *d_final, long long *d_steps)
+{
+    const size_t lds = image ? h->all_bytes : h->force_bytes;
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    int grid = 1, rc;
+    if (image) {
+        if ((rc = prep_kernel(k_const_fused<true>, lds))) return rc;
+        if ((rc = persistent_grid(h, k_const_fused<true>, BLOCK_PERSIST, lds, h->n_packets, &grid)))
+            return rc;
+        if ((rc = begin_timed(h))) return rc;
+        hipLaunchKernelGGL(k_const_fused<true>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
+                           h->F, h->G, h->d_blob, (int64_t)lds, h->n_packets, h->d_packets, step,
+                           n_iter, outeredge, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
+    } else {
+        if ((rc = prep_kernel(k_const_fused<false>, lds))) return rc;
+        if ((rc = persistent_grid(h, k_const_fused<false>, BLOCK_PERSIST, lds, h->n_packets,
+                                  &grid)))
+            return rc;
+        if ((rc = begin_timed(h))) return rc;
+        hipLaunchKernelGGL(k_const_fused<false>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
+                           h->F, h->G, h->d_blob, (int64_t)lds, h->n_packets, h->d_packets, step,
+                           n_iter, outeredge, d_final, d_steps, (double *)nullptr,
+                           (unsigned long long *)nullptr, h->d_ctr);
+    }
+    HIPCHK(hipGetLastError());
+    return end_timed(h);
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int nxc_abi_version(void) { return NXC_ABI_VERSION; }
+
+const char *nxc_last_error_string(void) { return g_error.c_str(); }
+
+int nxc_device_count(int *count)
+{
+    if (!count) return fail(NXC_ERR_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(NXC_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return NXC_OK;
+}
+
+int nxc_create(int device, nxc_handle **out)
+{
+    if (!out) return fail(NXC_ERR_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    int rc = nxc_device_count(&n);
+    if (rc) return rc;
+    if (n < 1) return fail(NXC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(NXC_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    nxc_handle *h = new (std::nothrow) nxc_handle();
+    if (!h) return fail(NXC_ERR_ARG, "out of host memory");
+    h->device = device;
+    h->n_cu = prop.multiProcessorCount;
+    std::snprintf(h->name, sizeof h->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+                  prop.multiProcessorCount);
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_ctr), sizeof(DevCounters));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_reduce), 64);
+    if (e == hipSuccess) e = hipMemset(h->d_ctr, 0, sizeof(DevCounters));
+    if (e != hipSuccess) {
+        nxc_destroy(h);
+        return fail(NXC_ERR_HIP, std::string("nxc_create: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return NXC_OK;
+}
+
+int nxc_destroy(nxc_handle *h)
+{
+    if (!h) return NXC_OK;
+    (void)hipSetDevice(h->device);
+    if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
+                    h->d_steps, h->d_reduce};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NXC_OK;
+}
+
+int nxc_device_name(nxc_handle *h, char *buf, int buflen)
+{
+    if (!h || !buf || buflen < 1) return fail(NXC_ERR_ARG, "bad arguments");
+    std::snprintf(buf, (size_t)buflen, "%s", h->name);
+    return NXC_OK;
+}
+
+int nxc_synchronize(nxc_handle *h)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
+{
+    if (!h || !f) return fail(NXC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    PackedLut lut;
+    const double zero_one[2] = {0.0, 1.0}, zeros[2] = {0.0, 0.0};
+    int rc;
+    if (f->radpres)
+        rc = pack_lut(f->v_tab, f->a_tab, f->n_tab, lut, "nxc_forces radiation table");
+    else
+        rc = pack_lut(zero_one, zeros, 2, lut, "placeholder table");
+    if (rc) return rc;
+    h->force_lut = std::move(lut);
+    h->F.GM = f->GM;
+    h->F.vrplanet = f->vrplanet;
+    h->F.photo = f->photo;
+    h->F.inv_lifetime = f->lifetime > 0 ? 1.0 / f->lifetime : 0.0;   // np.ones(n)/lifetime
+    h->F.grav = f->gravity ? 1 : 0;
+    h->F.rad = f->radpres ? 1 : 0;
+    h->F.loss = f->lifetime > 0 ? LOSS_LIFETIME : (f->has_photo ? LOSS_PHOTO : LOSS_NONE);
+    h->have_forces = true;
+    return upload_blob(h);
+}
+
+int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
+{
+    if (!h || !d) return fail(NXC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (d->nx < 1 || d->nz < 1 || d->nx > 32768 || d->nz > 32768 || !d->xedges || !d->zedges)
+        return fail(NXC_ERR_ARG, "image dims/edges invalid");
+    if (d->quantity != 0 && d->quantity != 1) return fail(NXC_ERR_ARG, "quantity must be 0 or 1");
+    const int nl = d->quantity == 1 ? d->n_lines : 0;
+    if (nl < 0 || nl > NXC_MAX_LINES) return fail(NXC_ERR_ARG, "n_lines out of range");
+    if (!(d->apix_cm2 > 0)) return fail(NXC_ERR_ARG, "apix_cm2 must be positive");
+    for (int64_t k = 0; k < d->nx; k++)
+        if (!(d->xedges[k + 1] > d->xedges[k])) return fail(NXC_ERR_ARG, "xedges not ascending");
+    for (int64_t k = 0; k < d->nz; k++)
+        if (!(d->zedges[k + 1] > d->zedges[k])) return fail(NXC_ERR_ARG, "zedges not ascending");
+
+    std::vector<unsigned char> part;
+    ImageK G{};
+    std::memcpy(G.M, d->M, sizeof G.M);
+    G.vrplanet = d->vrplanet;
+    G.apix_cm2 = d->apix_cm2;
+    G.quantity = d->quantity;
+    G.n_lines = nl;
+    G.downcast_f32 = d->downcast_f32 ? 1 : 0;
+    G.nx = (int)d->nx;
+    G.nz = (int)d->nz;
+    for (int l = 0; l < nl; l++) {
+        PackedLut lut;
+        int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
+        if (rc) return rc;
+        h->line_local[l] = lut.desc;
+        h->line_local[l].offset_bytes = (int64_t)part.size();
+        part.insert(part.end(), lut.bytes.begin(), lut.bytes.end());
+    }
+    h->xedges_local = (int64_t)part.size();
+    const unsigned char *xe = reinterpret_cast<const unsigned char *>(d->xedges);
+    part.insert(part.end(), xe, xe + (d->nx + 1) * sizeof(double));
+    h->zedges_local = (int64_t)part.size();
+    const unsigned char *ze = reinterpret_cast<const unsigned char *>(d->zedges);
+    part.insert(part.end(), ze, ze + (d->nz + 1) * sizeof(double));
+    G.x_lo = d->xedges[0];
+    G.x_inv_step = (double)d->nx / (d->xedges[d->nx] - d->xedges[0]);
+    G.z_lo = d->zedges[0];
+    G.z_inv_step = (double)d->nz / (d->zedges[d->nz] - d->zedges[0]);
+    h->image_part = std::move(part);
+    h->G = G;
+    h->have_image = true;
+
+    const size_t npix = (size_t)d->nx * (size_t)d->nz;
+    if (npix != h->npix) {
+        if (h->d_image) HIPCHK(hipFree(h->d_image));
+        if (h->d_counts) HIPCHK(hipFree(h->d_counts));
+        h->d_image = nullptr; h->d_counts = nullptr; h->npix = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_image), npix * sizeof(double)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_counts), npix * sizeof(unsigned long long)));
+        h->npix = npix;
+    }
+    int rc = upload_blob(h);
+    if (rc) return rc;
+    return nxc_image_clear(h);
+}
+
+int nxc_image_clear(nxc_handle *h)
+{
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(h->d_image, 0, h->npix * sizeof(double), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_counts, 0, h->npix * sizeof(unsigned long long), h->stream));
+    return NXC_OK;
+}
+
+int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
+{
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    if (image)
+        HIPCHK(hipMemcpyAsync(image, h->d_image, h->npix * sizeof(double), hipMemcpyDeviceToHost,
+                              h->stream));
+    if (counts)
+        HIPCHK(hipMemcpyAsync(counts, h->d_counts, h->npix * sizeof(uint64_t),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_counters_get(nxc_handle *h, nxc_counters *out)
+{
+    if (!h || !out) return fail(NXC_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    DevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out->particle_steps = c.particle_steps;
+    out->samples = c.samples;
+    out->samples_binned = c.samples_binned;
+    out->nonfinite = c.nonfinite;
+    out->bad_step = c.bad_step;
+    out->neg_frac = c.neg_frac;
+    out->unfinished = c.unfinished;
+    out->reserved = 0;
+    return NXC_OK;
+}
+
+int nxc_last_kernel_ms(nxc_handle *h, float *ms)
+{
+    if (!h || !ms) return fail(NXC_ERR_ARG, "null argument");
+    if (!h->timed) return fail(NXC_ERR_STATE, "no timed launch yet");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return NXC_OK;
+}
+
+int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const double *z,
+              const double *vy, double *ax, double *ay, double *az, double *ioniz)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    if (n < 0 || (n && (!x || !y || !z || !vy || !ax || !ay || !az || !ioniz)))
+        return fail(NXC_ERR_ARG, "bad arguments");
+    if (n == 0) return NXC_OK;
+    const size_t bytes = (size_t)n * sizeof(double);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * bytes)))
+        return rc;
+    double *d = h->d_scratch;
+    const double *src[4] = {x, y, z, vy};
+    for (int c = 0; c < 4; c++)
+        HIPCHK(hipMemcpyAsync(d + c * n, src[c], bytes, hipMemcpyHostToDevice, h->stream));
+    if ((rc = prep_kernel(k_state, h->force_bytes))) return rc;
+    hipLaunchKernelGGL(k_state, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), h->force_bytes,
+                       h->stream, h->F, h->d_blob, (int64_t)h->force_bytes, n, d, d + n, d + 2 * n,
+                       d + 3 * n, d + 4 * n, d + 5 * n, d + 6 * n, d + 7 * n);
+    HIPCHK(hipGetLastError());
+    double *dst[4] = {ax, ay, az, ioniz};
+    for (int c = 0; c < 4; c++)
+        HIPCHK(hipMemcpyAsync(dst[c], d + (4 + c) * n, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *hstep,
+                 double *soa_out, double *delta_out)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    if (n < 0 || (n && (!soa_in || !hstep || !soa_out))) return fail(NXC_ERR_ARG, "bad arguments");
+    if (n == 0) return NXC_OK;
+    const size_t col = (size_t)n * sizeof(double);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 25 * col)))
+        return rc;
+    double *d_in = h->d_scratch, *d_h = d_in + 8 * n, *d_out = d_h + n, *d_delta = d_out + 8 * n;
+    HIPCHK(hipMemcpyAsync(d_in, soa_in, 8 * col, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_h, hstep, col, hipMemcpyHostToDevice, h->stream));
+    const int grid = flat_grid(h, n, NXC_BLOCK);
+    if (delta_out) {
+        if ((rc = prep_kernel(k_rk5_step<true>, h->force_bytes))) return rc;
+        hipLaunchKernelGGL(k_rk5_step<true>, dim3(grid), dim3(NXC_BLOCK), h->force_bytes,
+                           h->stream, h->F, h->d_blob, (int64_t)h->force_bytes, n, d_in, d_h,
+                           d_out, d_delta);
+    } else {
+        if ((rc = prep_kernel(k_rk5_step<false>, h->force_bytes))) return rc;
+        hipLaunchKernelGGL(k_rk5_step<false>, dim3(grid), dim3(NXC_BLOCK), h->force_bytes,
+                           h->stream, h->F, h->d_blob, (int64_t)h->force_bytes, n, d_in, d_h,
+                           d_out, d_delta);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(soa_out, d_out, 8 * col, hipMemcpyDeviceToHost, h->stream));
+    if (delta_out)
+        HIPCHK(hipMemcpyAsync(delta_out, d_delta, 8 * col, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
+{
+    if (!h || n < 0 || (n && !soa0)) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)8 * n * sizeof(double);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(h->d_packets, soa0, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->n_packets = n;
+    return NXC_OK;
+}
+
+int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                              uint32_t flags)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    if (h->n_packets < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
+    if (!(step > 0) || n_iter < 0) return fail(NXC_ERR_ARG, "step must be > 0, n_iter >= 0");
+    const bool image = (flags & NXC_RUN_IMAGE) != 0;
+    if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
+    return launch_const(h, step, n_iter, outeredge, image, nullptr, nullptr);
+}
+
+int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                        uint32_t flags, double *traj_out, int64_t nrec, double *final_out,
+                        int64_t *steps_out)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    const int64_t n = h->n_packets;
+    if (n < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
+    if (!(step > 0) || n_iter < 0) return fail(NXC_ERR_ARG, "step must be > 0, n_iter >= 0");
+    const bool image = (flags & NXC_RUN_IMAGE) != 0;
+    if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
+    if (traj_out && nrec < n_iter + 1) return fail(NXC_ERR_ARG, "nrec must be >= n_iter + 1");
+
+    const size_t col = (size_t)n * sizeof(double);
+    double *d_final = nullptr;
+    long long *d_steps = nullptr;
+    if (final_out) {
+        if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col)))
+            return rc;
+        d_final = h->d_scratch;
+    }
+    if (steps_out) {
+        if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
+                         (size_t)n * sizeof(long long))))
+            return rc;
+        d_steps = h->d_steps;
+    }
+    if (!traj_out) {
+        if ((rc = launch_const(h, step, n_iter, outeredge, image, d_final, d_steps))) return rc;
+    } else {
+        const size_t tbytes = (size_t)8 * (size_t)nrec * col;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        if (tbytes > free_b)
+            return fail(NXC_ERR_ARG, "trajectory buffer does not fit in device memory; run fewer "
+                                     "packets per call (the reference chunks too, Input.py:219-222)");
+        double *d_traj = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes));
+        hipError_t e = hipMemsetAsync(d_traj, 0, tbytes, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
+        const size_t lds = image ? h->all_bytes : h->force_bytes;
+        const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
+        if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+        if (e == hipSuccess) {
+            if (image) {
+                rc = prep_kernel(k_const_traj<true>, lds);
+                if (!rc)
+                    hipLaunchKernelGGL(k_const_traj<true>, dim3(grid), dim3(NXC_BLOCK), lds,
+                                       h->stream, h->F, h->G, h->d_blob, (int64_t)lds, n,
+                                       h->d_packets, step, n_iter, outeredge, d_traj, nrec, d_final,
+                                       d_steps, h->d_image, h->d_counts, h->d_ctr);
+            } else {
+                rc = prep_kernel(k_const_traj<false>, lds);
+                if (!rc)
+                    hipLaunchKernelGGL(k_const_traj<false>, dim3(grid), dim3(NXC_BLOCK), lds,
+                                       h->stream, h->F, h->G, h->d_blob, (int64_t)lds, n,
+                                       h->d_packets, step, n_iter, outeredge, d_traj, nrec, d_final,
+                                       d_steps, (double *)nullptr, (unsigned long long *)nullptr,
+                                       h->d_ctr);
+            }
+            if (!rc) e = hipGetLastError();
+        }
+        if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
+        if (e == hipSuccess && !rc) {
+            h->timed = true;
+            e = hipMemcpyAsync(traj_out, d_traj, tbytes, hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_traj);
+        if (rc) return rc;
+        if (e != hipSuccess)
+            return fail(NXC_ERR_HIP, std::string("trajectory run: ") + hipGetErrorString(e));
+    }
+    if (final_out)
+        HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));
+    if (steps_out)
+        HIPCHK(hipMemcpyAsync(steps_out, d_steps, (size_t)n * sizeof(long long),
+                              hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,
+                      double *final_out, double *hstore_out)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    const int64_t n = h->n_packets;
+    if (n < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
+    if (!(resolution > 0) || !final_out || max_steps < 1) return fail(NXC_ERR_ARG, "bad arguments");
+    const size_t col = (size_t)n * sizeof(double);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 9 * col)))
+        return rc;
+    double *d_final = h->d_scratch, *d_hs = d_final + 8 * n;
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    int grid = 1;
+    const size_t lds = h->force_bytes;
+    if ((rc = prep_kernel(k_var, lds))) return rc;
+    if ((rc = persistent_grid(h, k_var, BLOCK_PERSIST, lds, n, &grid))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(k_var, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
+                       (int64_t)lds, n, h->d_packets, resolution, outeredge, (long long)max_steps,
+                       d_final, d_hs, h->d_ctr);
+    HIPCHK(hipGetLastError());
+    if ((rc = end_timed(h))) return rc;
+    HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));
+    if (hstore_out)
+        HIPCHK(hipMemcpyAsync(hstore_out, d_hs, col, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
+                         const double *z, const double *vy, const double *frac)
+{
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    if (p < 0 || (p && (!x || !y || !z || !vy || !frac))) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    if (p == 0) return NXC_OK;
+    const size_t col = (size_t)p * sizeof(double);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 5 * col);
+    if (rc) return rc;
+    double *d = h->d_scratch;
+    const double *src[5] = {x, y, z, vy, frac};
+    for (int c = 0; c < 5; c++)
+        HIPCHK(hipMemcpyAsync(d + c * p, src[c], col, hipMemcpyHostToDevice, h->stream));
+    if ((rc = prep_kernel(k_image, h->all_bytes))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(k_image, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
+                       h->stream, h->G, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
+                       d + 3 * p, d + 4 * p, h->d_image, h->d_counts, h->d_ctr);
+    HIPCHK(hipGetLastError());
+    if ((rc = end_timed(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+// ---- RCCL -------------------------------------------------------------------------------------
+int nxc_comm_unique_id(uint8_t id[NXC_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == NXC_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!id) return fail(NXC_ERR_ARG, "id is null");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return NXC_OK;
+}
+
+int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank, int nranks)
+{
+    if (!h || !id || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(NXC_ERR_ARG, "bad arguments");
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    h->rank = rank;
+    h->nranks = nranks;
+    return NXC_OK;
+}
+
+int nxc_comm_destroy(nxc_handle *h)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    if (h->comm && g_rccl.ok) {
+        HIPCHK(hipSetDevice(h->device));
+        NCCLCHK(g_rccl.CommDestroy(h->comm));
+    }
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    return NXC_OK;
+}
+
+int nxc_image_allreduce(nxc_handle *h)
+{
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    NCCLCHK(g_rccl.AllReduce(h->d_image, h->d_image, h->npix, ncclFloat64, ncclSum, h->comm,
+                             h->stream));
+    NCCLCHK(g_rccl.AllReduce(h->d_counts, h->d_counts, h->npix, ncclUint64, ncclSum, h->comm,
+                             h->stream));
+    return NXC_OK;
+}
+
+int nxc_allreduce_max_f64(nxc_handle *h, double *value)
+{
+    if (!h || !value) return fail(NXC_ERR_ARG, "null argument");
+    if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(h->d_reduce, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    NCCLCHK(g_rccl.AllReduce(h->d_reduce, h->d_reduce, 1, ncclFloat64, ncclMax, h->comm,
+                             h->stream));
+    HIPCHK(hipMemcpyAsync(value, h->d_reduce, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_barrier(nxc_handle *h)
+{
+    double v = 0.0;
+    return nxc_allreduce_max_f64(h, &v);
+}
+
+int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const double *in2,
+                   double *out)
+{
+    if (!h || n < 0 || (n && (!in || !out)) || which < 0 || which > 4 || (which == 4 && !in2))
+        return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (n == 0) return NXC_OK;
+    const size_t col = (size_t)n * sizeof(double);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 3 * col);
+    if (rc) return rc;
+    double *d = h->d_scratch;
+    HIPCHK(hipMemcpyAsync(d, in, col, hipMemcpyHostToDevice, h->stream));
+    if (in2) HIPCHK(hipMemcpyAsync(d + n, in2, col, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_math, dim3(flat_grid(h, n, 256)), dim3(256), 0, h->stream, which, n, d,
+                       d + n, d + 2 * n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d + 2 * n, col, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// nxc_device.hpp -- device-side building blocks shared by every kernel of the hot path:
+// LDS-resident lookup tables with np.interp semantics, the force/loss model, one Dormand-Prince
+// step, the post-step fate tests and the per-sample image accumulation.
+//
+// Arithmetic contract: every expression below is written in the reference's operation order and
+// the translation unit is compiled with -ffp-contract=off, so each fp64 operation rounds exactly
+// once, as NumPy's element-wise kernels do.  Citations are paths under the reference tree's
+// nexoclom/ directory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nxc_math.hpp"
+
+// ---------------------------------------------------------------------------------------------
+// Lookup table with np.interp semantics (numpy compiled_base.c arr_interp): clamp to the end
+// values outside the table, fp[j] when x hits a node, else slope_j*(x - xp[j]) + fp[j] with
+// slope_j = (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) (computed once on the host: same IEEE quotient).
+//
+// Global image of one table (doubles unless noted), staged verbatim into LDS:
+//   [0 .. n)        xp
+//   [n .. 2n)       fp
+//   [2n .. 3n)      slope (last entry unused)
+//   then (ncell+1) uint16 cell->index entries, padded to a multiple of 8 bytes.
+// cell[c] is an index j with xp[j] <= left edge of uniform cell c (a lower bound good to a few
+// entries); the search walks from there, so the result is exactly the j of a bisection whatever
+// the rounding of the cell computation.
+// ---------------------------------------------------------------------------------------------
+struct LutDesc {          // host-filled, passed by value in kernel arguments
+    int n;                // table length
+    int ncell;            // number of uniform cells over [x0, xlast]
+    double x0, xlast;     // xp[0], xp[n-1]
+    double inv_w;         // ncell / (xlast - x0)
+    int64_t offset_bytes; // byte offset of this table inside the packed table blob
+    int64_t size_bytes;   // bytes of this table in the blob (multiple of 8)
+};
+
+// All tables live in the workgroup's dynamic LDS block; they are addressed by byte offset from
+// its base so that every access is visibly an LDS (ds_read) access to the compiler.
+extern __shared__ __align__(16) unsigned char nxc_lds[];
+
+NXC_DEV double lds_f64(int byte_off)
+{
+    return *reinterpret_cast<const double *>(nxc_lds + byte_off);
+}
+NXC_DEV int lds_u16(int byte_off)
+{
+    return *reinterpret_cast<const unsigned short *>(nxc_lds + byte_off);
+}
+
+struct LutView {          // byte offsets into the LDS block
+    int xp, fp, sl, cell;
+    int n, ncell;
+    double x0, xlast, inv_w;
+};
+
+NXC_DEV LutView lut_view(const LutDesc &d)
+{
+    LutView v;
+    v.xp = (int)d.offset_bytes;
+    v.fp = v.xp + 8 * d.n;
+    v.sl = v.xp + 16 * d.n;
+    v.cell = v.xp + 24 * d.n;
+    v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast; v.inv_w = d.inv_w;
+    return v;
+}
+
+NXC_DEV double lut_interp(const LutView &t, double x)
+{
+    if (x != x) return x;
+    if (x > t.xlast) return lds_f64(t.fp + 8 * (t.n - 1));
+    if (x < t.x0) return lds_f64(t.fp);
+    int c = (int)((x - t.x0) * t.inv_w);
+    c = c < t.ncell ? c : t.ncell - 1;
+    int j = lds_u16(t.cell + 2 * c);
+    while (j > 0 && lds_f64(t.xp + 8 * j) > x) --j;
+    while (j + 1 < t.n && lds_f64(t.xp + 8 * (j + 1)) <= x) ++j;
+    const double xj = lds_f64(t.xp + 8 * j);
+    const double fj = lds_f64(t.fp + 8 * j);
+    if (j == t.n - 1 || xj == x) return fj;
+    return lds_f64(t.sl + 8 * j) * (x - xj) + fj;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Force / loss model: particle_tracking/state.py:17-74
+// ---------------------------------------------------------------------------------------------
+enum : int { LOSS_NONE = 0, LOSS_LIFETIME = 1, LOSS_PHOTO = 2 };
+
+struct ForceK {           // kernel-argument copy of nxc_forces' scalars
+    double GM, vrplanet, photo, inv_lifetime;
+    int grav, rad, loss, pad_;   // wave-uniform switches (inputs.forces.*, lifetime/photo mode)
+    LutDesc tab;                 // radiation-acceleration table inside the blob
+};
+
+// (sqrt(x*x + z*z) > 1) | (y < 0)  (state.py:28-29,50-51).  For a correctly rounded sqrt,
+// sqrt(s) > 1  <=>  s > 1 + 2^-52 (sqrt(1+2^-52) rounds to 1), so the root is not taken.
+NXC_DEV bool sunlit(double x, double y, double z)
+{
+    double s = x * x + z * z;
+    return (s > 0x1.0000000000001p+0) || (y < 0.0);
+}
+
+NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, double z, double vy,
+                        double &ax, double &ay, double &az, double &ion)
+{
+    double gx = 0.0, gy = 0.0, gz = 0.0;
+    if (F.grav) {                                         // state.py:19-21
+        double r3 = nxc_cube(__builtin_sqrt((x * x + y * y) + z * z));
+        gx = F.GM * x / r3;
+        gy = F.GM * y / r3;
+        gz = F.GM * z / r3;
+    }
+    const bool lit = sunlit(x, y, z);
+    double ry = 0.0;
+    if (F.rad) {                                          // state.py:27-36
+        double vv = vy + F.vrplanet;
+        ry = lut_interp(T, vv) * (lit ? 1.0 : 0.0);
+    }
+    ax = gx + 0.0;                                        // state.py:41
+    ay = gy + ry;
+    az = gz + 0.0;
+    if (F.loss == LOSS_LIFETIME) ion = F.inv_lifetime;    // state.py:44-46
+    else if (F.loss == LOSS_PHOTO) ion = F.photo * (lit ? 1.0 : 0.0);   // state.py:48-52
+    else ion = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dormand-Prince tableau (rk5.py:5-18) and one step (rk5.py:21-54)
+// ---------------------------------------------------------------------------------------------
+struct Tableau {
+    static constexpr double A[7][7] = {
+        {0, 0, 0, 0, 0, 0, 0},
+        {0.2, 0, 0, 0, 0, 0, 0},
+        {3. / 40., 9. / 40., 0, 0, 0, 0, 0},
+        {44. / 45., -56. / 15., 32. / 9., 0, 0, 0, 0},
+        {19372. / 6561., -25360. / 2187., 64448. / 6561., -212. / 729., 0, 0, 0},
+        {9017. / 3168., -355. / 33., 46732. / 5247., 49. / 176., -5103. / 18656., 0, 0},
+        {35. / 384., 0., 500. / 1113., 125. / 192., -2187. / 6784., 11. / 84., 0.}};
+    static constexpr double B5[7] = {35. / 384., 0., 500. / 1113., 125. / 192., -2187. / 6784.,
+                                     11. / 84., 0.};
+    static constexpr double B4[7] = {5179. / 57600., 0., 7571. / 16695., 393. / 640.,
+                                     -92097. / 339200., 187. / 2100., 1. / 40.};
+};
+
+// s[8] = t_remaining, x, y, z, vx, vy, vz, frac (in/out).  d[8] (DELTA only) = the reference's
+// error estimate |h * sum_{i<6} (B5-B4)_i k_i| (rk5.py:38-46; the 7th stage is left out there).
+// Each stage is accumulated from zero in the order i = 0..n with terms (h*a)*k and the initial
+// state added last (rk5.py:32-36); frac is carried as log(frac) (rk5.py:25,35,50).
+template <bool DELTA>
+NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double h, double (&d)[8])
+{
+    double kv[6][3], ka[6][3], kl[6];
+    const double x0 = s[1], y0 = s[2], z0 = s[3], vx0 = s[4], vy0 = s[5], vz0 = s[6];
+    const double lf0 = nxc_log(s[7]);
+    double px = x0, py = y0, pz = z0, vx = vx0, vy = vy0, vz = vz0, lf = lf0;
+#pragma unroll
+    for (int n = 0; n < 6; n++) {
+        kv[n][0] = vx; kv[n][1] = vy; kv[n][2] = vz;
+        state_eval(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
+        double nx = 0.0, ny = 0.0, nz = 0.0, nvx = 0.0, nvy = 0.0, nvz = 0.0, nlf = 0.0;
+#pragma unroll
+        for (int i = 0; i <= n; i++) {
+            const double w = h * Tableau::A[n + 1][i];
+            nx += w * kv[i][0];
+            ny += w * kv[i][1];
+            nz += w * kv[i][2];
+            nvx += w * ka[i][0];
+            nvy += w * ka[i][1];
+            nvz += w * ka[i][2];
+            nlf -= w * kl[i];
+        }
+        px = nx + x0; py = ny + y0; pz = nz + z0;
+        vx = nvx + vx0; vy = nvy + vy0; vz = nvz + vz0;
+        lf = nlf + lf0;
+    }
+    if (DELTA) {
+        double e[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double bd = Tableau::B5[i] - Tableau::B4[i];
+            e[0] += bd * kv[i][0];
+            e[1] += bd * kv[i][1];
+            e[2] += bd * kv[i][2];
+            e[3] += bd * ka[i][0];
+            e[4] += bd * ka[i][1];
+            e[5] += bd * ka[i][2];
+            e[6] += bd * kl[i];
+        }
+        d[0] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 7; c++) d[c + 1] = __builtin_fabs(h * e[c]);
+    }
+    s[0] = (-h) + s[0];            // -h*c[6] + t, c[6] = 1 (rk5.py:31,36)
+    s[1] = px; s[2] = py; s[3] = pz; s[4] = vx; s[5] = vy; s[6] = vz;
+    s[7] = nxc_exp(lf);
+}
+
+// Post-step tests with stickcoef == 1.  Constant driver: Output.py:395-416 (r = |x|); variable
+// driver: Output.py:308-324, which compares r^2 with 1 AND with outeredge (reference quirk).
+// (sqrt(r2) - 1) < 0  <=>  r2 < 1 for a correctly rounded sqrt.
+template <bool R_SQUARED>
+NXC_DEV void apply_fate(double (&s)[8], double outeredge)
+{
+    double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
+    double rr = R_SQUARED ? r2 : __builtin_sqrt(r2);
+    if (r2 < 1.0) s[7] = 0.0;
+    if (rr > outeredge) s[7] = 0.0;
+    if (s[7] < 1e-10) s[7] = 0.0;
+    if (s[7] == 0.0) s[0] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image: data_simulation/ModelImage.py:242-269, ModelResult.py:140-170, math/histogram.py:32-36
+// ---------------------------------------------------------------------------------------------
+struct ImageK {            // kernel-argument scalars of nxc_image_desc
+    double M[9];
+    double vrplanet, apix_cm2;
+    int quantity, n_lines, downcast_f32, pad_;
+    int nx, nz;
+    double x_lo, x_inv_step, z_lo, z_inv_step;   // only to seed the edge search
+    int64_t xedges_off, zedges_off;              // byte offsets of the edge arrays in the blob
+    LutDesc line[4];
+};
+
+// np.histogram2d bin along one axis: searchsorted(edges, v, 'right') - 1, the right-most edge
+// folded into the last bin, everything else (NaN included) outside = -1.  The arithmetic guess
+// is corrected against the very edge values np.linspace produced (staged in LDS).
+NXC_DEV int bin_index(double v, int edges, int n, double lo, double inv_step)
+{
+    if (!(v >= lds_f64(edges)) || !(v <= lds_f64(edges + 8 * n))) return -1;
+    int k = (int)((v - lo) * inv_step);
+    k = k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
+    while (k > 0 && v < lds_f64(edges + 8 * k)) --k;
+    while (k < n - 1 && v >= lds_f64(edges + 8 * (k + 1))) ++k;
+    return k;
+}
+
+NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
+
+// Adds one sample to the image pair.  Returns 1 if the sample fell inside the image.
+// The fp64 add is the hardware global_atomic_add_f64; counts are 64-bit integer atomics.
+NXC_DEV int image_sample(const ImageK &G, double x, double y, double z,
+                         double vy, double frac, double *image, unsigned long long *counts,
+                         unsigned long long &nonfinite)
+{
+    if (G.downcast_f32) {
+        x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
+        vy = f32_round_trip(vy); frac = f32_round_trip(frac);
+    }
+    const double radvel = vy + G.vrplanet;                         // ModelImage.py:242-243
+    const double xo = (G.M[0] * x + G.M[1] * y) + G.M[2] * z;      // ModelImage.py:249
+    const double yo = (G.M[3] * x + G.M[4] * y) + G.M[5] * z;
+    const double zo = (G.M[6] * x + G.M[7] * y) + G.M[8] * z;
+    const double s_obs = xo * xo + zo * zo;                        // ModelImage.py:252-254
+    const bool inview = (s_obs > 0x1.0000000000001p+0) || (yo < 0.0);
+    frac = frac * (inview ? 1.0 : 0.0);
+    double w;
+    if (G.quantity == 0) {                                         // ModelResult.py:148-149
+        w = frac;
+    } else {                                                       // ModelResult.py:150-161
+        double gg = 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; l++)
+            if (l < G.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
+        w = frac * (sunlit(x, y, z) ? 1.0 : 0.0) * gg / 1e6;
+    }
+    w = w / G.apix_cm2;                                            // ModelImage.py:262
+    if (!(__builtin_fabs(w) <= 1.7976931348623157e308)) nonfinite++;   // ModelResult.py:170
+    const int ix = bin_index(xo, (int)G.xedges_off, G.nx, G.x_lo, G.x_inv_step);
+    const int iz = bin_index(zo, (int)G.zedges_off, G.nz, G.z_lo, G.z_inv_step);
+    if (ix < 0 || iz < 0) return 0;
+    const int64_t pix = (int64_t)ix * G.nz + iz;
+    if (w != 0.0) unsafeAtomicAdd(&image[pix], w);
+    atomicAdd(&counts[pix], 1ull);
+    return 1;
+}

@@ -1,0 +1,381 @@
+// nxc_kernels.hpp -- the gfx950 kernels of the nexoclom hot path.
+//
+//   k_state         a-2  element-wise force/loss model
+//   k_rk5_step      a-1  one Dormand-Prince step per packet, per-packet step size
+//   k_const_traj    a-3  lock-step constant-step driver that streams every record to HBM
+//                        ([column][record][packet]: each store is coalesced across the wave)
+//   k_const_fused   a-3 + a-6..a-8  persistent LANE-REFILL integrator: a lane keeps its packet's
+//                        state in registers until the packet dies, then takes the next packet
+//                        from a global queue (claimed in chunks, handed out inside the wave by
+//                        ballot + prefix rank), so waves stay full although lifetimes differ by
+//                        three orders of magnitude.  Every stored record is binned straight into
+//                        the image; the (N, 8, nsteps) trajectory tensor is never materialised.
+//   k_var           a-4  adaptive-step driver, same lane-refill structure
+//   k_image         a-6..a-8  image of stored samples (HBM-bound: 40 B/sample in)
+//
+// All lookup tables (radiation acceleration, g-values, bin edges) are staged once per workgroup
+// into LDS from one packed blob.
+#pragma once
+#include "nxc_device.hpp"
+
+struct DevCounters {
+    unsigned long long particle_steps, samples, samples_binned, nonfinite, bad_step, neg_frac,
+        unfinished, queue_head;
+};
+
+constexpr int NXC_BLOCK = 256;      // threads per workgroup (4 waves)
+constexpr int NXC_CHUNK = 128;      // packets claimed from the global queue per atomic
+
+// Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS.
+NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
+{
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(blob);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(nxc_lds);
+    const int64_t words = bytes >> 3;
+    for (int64_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    __syncthreads();
+}
+
+NXC_DEV unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+NXC_DEV void flush_counter(unsigned long long *dst, unsigned long long v)
+{
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+NXC_DEV long long wave_bcast0(long long v)
+{
+    int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+    int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_state(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
+        const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+        const double *__restrict__ vy, double *__restrict__ ax, double *__restrict__ ay,
+        double *__restrict__ az, double *__restrict__ ion)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double a0, a1, a2, l;
+        state_eval(F, T, x[i], y[i], z[i], vy[i], a0, a1, a2, l);
+        ax[i] = a0; ay[i] = a1; az[i] = a2; ion[i] = l;
+    }
+}
+
+template <bool DELTA>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
+           const double *__restrict__ in, const double *__restrict__ hstep,
+           double *__restrict__ out, double *__restrict__ delta)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double s[8], d[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) s[c] = in[c * n + i];
+        rk5_step<DELTA>(F, T, s, hstep[i], d);
+#pragma unroll
+        for (int c = 0; c < 8; c++) out[c * n + i] = s[c];
+        if (DELTA) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) delta[c * n + i] = d[c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lock-step driver with trajectory output.  traj is pre-zeroed: dead packets leave zero records,
+// like the reference's `results` (Output.py:376).
+template <bool IMAGE>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_const_traj(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes,
+             int64_t n, const double *__restrict__ soa0, double step, int64_t n_iter,
+             double outeredge, double *__restrict__ traj, int64_t nrec,
+             double *__restrict__ final_out, long long *__restrict__ steps_out,
+             double *__restrict__ image, unsigned long long *__restrict__ counts,
+             DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double s[8], d[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) s[c] = soa0[c * n + i];
+#pragma unroll
+        for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec) * n + i] = s[c];
+        bool alive = s[7] > 0.0;
+        if (IMAGE && alive) {
+            my_samples++;
+            my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                                      my_nonfinite);
+        }
+        long long k = 0;
+        while (alive && k < n_iter) {
+            rk5_step<false>(F, T, s, step, d);
+            apply_fate<false>(s, outeredge);
+            k++; my_steps++;
+            if (k < nrec) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec + k) * n + i] = s[c];
+            }
+            alive = s[7] > 0.0;
+            if (IMAGE && alive) {
+                my_samples++;
+                my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                                          my_nonfinite);
+            }
+        }
+        if (final_out) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) final_out[c * n + i] = s[c];
+        }
+        if (steps_out) steps_out[i] = k;
+    }
+    flush_counter(&ctr->particle_steps, my_steps);
+    if (IMAGE) {
+        flush_counter(&ctr->samples, my_samples);
+        flush_counter(&ctr->samples_binned, my_binned);
+        flush_counter(&ctr->nonfinite, my_nonfinite);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-level packet queue: lanes without a packet are served from the wave's current chunk
+// [c_next, c_end) in lane order (prefix rank over the ballot); an exhausted chunk is replaced by
+// one atomicAdd of NXC_CHUNK on the global head.  All control flow here is wave-uniform.
+// Returns the packet index for this lane or -1.
+struct WaveQueue {
+    long long c_next = 0, c_end = 0;
+    bool drained = false;
+
+    NXC_DEV long long refill(bool need, unsigned long long *head, long long n)
+    {
+        const unsigned long long mask = __ballot(need);
+        long long mine = -1;
+        if (mask == 0 || drained) return mine;
+        const int want = __popcll(mask);
+        const int lane = threadIdx.x & 63;
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        int served = 0;
+        while (served < want) {
+            if (c_next >= c_end) {
+                long long b = 0;
+                if (lane == 0) b = (long long)atomicAdd(head, (unsigned long long)NXC_CHUNK);
+                b = wave_bcast0(b);
+                if (b >= n) { drained = true; break; }
+                c_next = b;
+                c_end = (b + NXC_CHUNK < n) ? b + NXC_CHUNK : n;
+            }
+            const long long room = c_end - c_next;
+            const int take = room < (long long)(want - served) ? (int)room : want - served;
+            if (need && rank >= served && rank < served + take) mine = c_next + (rank - served);
+            c_next += take;
+            served += take;
+        }
+        return mine;
+    }
+};
+
+// Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
+// machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
+// is drained and none of its lanes holds a live packet.
+template <bool IMAGE>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_const_fused(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes,
+              int64_t n, const double *__restrict__ soa0, double step, int64_t n_iter,
+              double outeredge, double *__restrict__ final_out,
+              long long *__restrict__ steps_out, double *__restrict__ image,
+              unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
+    WaveQueue q;
+    bool has = false;
+    long long id = -1, k = 0;
+    double s[8], d[8];
+    for (;;) {
+        const long long got = q.refill(!has, &ctr->queue_head, n);
+        if (got >= 0) {
+            id = got; k = 0; has = true;
+#pragma unroll
+            for (int c = 0; c < 8; c++) s[c] = soa0[c * n + id];
+            if (IMAGE && s[7] > 0.0) {
+                my_samples++;
+                my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                                          my_nonfinite);
+            }
+        }
+        if (__ballot(has) == 0) break;
+        if (has) {
+            bool done = !(s[7] > 0.0) || k >= n_iter;
+            if (!done) {
+                rk5_step<false>(F, T, s, step, d);
+                apply_fate<false>(s, outeredge);
+                k++; my_steps++;
+                if (s[7] > 0.0) {
+                    if (IMAGE) {
+                        my_samples++;
+                        my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image,
+                                                  counts, my_nonfinite);
+                    }
+                    done = k >= n_iter;
+                } else {
+                    done = true;
+                }
+            }
+            if (done) {
+                if (final_out) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) final_out[c * n + id] = s[c];
+                }
+                if (steps_out) steps_out[id] = k;
+                has = false;
+            }
+        }
+    }
+    flush_counter(&ctr->particle_steps, my_steps);
+    if (IMAGE) {
+        flush_counter(&ctr->samples, my_samples);
+        flush_counter(&ctr->samples_binned, my_binned);
+        flush_counter(&ctr->nonfinite, my_nonfinite);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adaptive-step driver (Output.py:221-359), one rk5 attempt per loop trip, lane-refill as above.
+//   h = min(t_remaining, stored step)                                   :253
+//   errmax = max_c delta_c / (res_c + |y_c| res_c), res_v = 0.1 res     :235-238,271-281
+//   frac-increase guard -> errmax = 1.1                                  :291
+//   errmax < 1e-7 -> errmax = 1 and h*10, which lands in the REJECT branch (errmax >= 1)  :294-300
+//   accept (errmax < 1): fate tests on r^2; the grown step is never stored  :302-327
+//   reject: stored step = max(0.95 h errmax^-0.25, 0.1 h)               :333-342
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
+      const double *__restrict__ soa0, double resolution, double outeredge, long long max_steps,
+      double *__restrict__ final_out, double *__restrict__ hstore_out,
+      DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
+    unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
+    WaveQueue q;
+    bool has = false;
+    long long id = -1, it = 0;
+    double s[8], hs = 1000.0;
+    for (;;) {
+        const long long got = q.refill(!has, &ctr->queue_head, n);
+        if (got >= 0) {
+            id = got; it = 0; hs = 1000.0; has = true;
+#pragma unroll
+            for (int c = 0; c < 8; c++) s[c] = soa0[c * n + id];
+        }
+        if (__ballot(has) == 0) break;
+        if (has) {
+            bool done = !(s[0] > resolution && s[7] > 0.0);
+            if (!done && it >= max_steps) { my_unfinished++; done = true; }
+            if (!done) {
+                const double h = __builtin_fmin(s[0], hs);
+                if (!(h > 0.0)) { my_bad++; done = true; }
+                else {
+                    double t[8], d[8];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) t[c] = s[c];
+                    rk5_step<true>(F, T, t, h, d);
+                    my_steps++; it++;
+                    const double fscale = resf + __builtin_fabs(t[7]) * resf;
+                    double e = d[0];
+#pragma unroll
+                    for (int c = 1; c <= 3; c++)
+                        e = __builtin_fmax(e, d[c] / (resx + __builtin_fabs(t[c]) * resx));
+#pragma unroll
+                    for (int c = 4; c <= 6; c++)
+                        e = __builtin_fmax(e, d[c] / (resv + __builtin_fabs(t[c]) * resv));
+                    e = __builtin_fmax(e, d[7] / fscale);
+                    if (!(__builtin_fabs(e) <= 1.7976931348623157e308)) { my_nonfinite++; done = true; }
+                    else {
+                        if (t[7] < 0.0 && e < 1.0) my_neg++;
+                        if ((t[7] - s[7] > fscale) && (e > 1.0)) e = 1.1;
+                        double hold = h;
+                        if (e < 1e-7) { e = 1.0; hold = h * 10; }
+                        if (e < 1.0) {
+                            apply_fate<true>(t, outeredge);
+#pragma unroll
+                            for (int c = 0; c < 8; c++) s[c] = t[c];
+                        } else {
+                            const double hn = 0.95 * hold * nxc_pow_m025(e);
+                            if (!(__builtin_fabs(hn) <= 1.7976931348623157e308)) { my_bad++; done = true; }
+                            else hs = __builtin_fmax(hn, 0.1 * hold);
+                        }
+                    }
+                }
+            }
+            if (done) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) final_out[c * n + id] = s[c];
+                if (hstore_out) hstore_out[id] = hs;
+                has = false;
+            }
+        }
+    }
+    flush_counter(&ctr->particle_steps, my_steps);
+    flush_counter(&ctr->nonfinite, my_nonfinite);
+    flush_counter(&ctr->bad_step, my_bad);
+    flush_counter(&ctr->neg_frac, my_neg);
+    flush_counter(&ctr->unfinished, my_unfinished);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_image(ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
+        const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+        const double *__restrict__ vy, const double *__restrict__ frac,
+        double *__restrict__ image, unsigned long long *__restrict__ counts,
+        DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);
+    unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        my_samples++;
+        my_binned += image_sample(G, x[i], y[i], z[i], vy[i], frac[i], image, counts,
+                                  my_nonfinite);
+    }
+    flush_counter(&ctr->samples, my_samples);
+    flush_counter(&ctr->samples_binned, my_binned);
+    flush_counter(&ctr->nonfinite, my_nonfinite);
+}
+
+__global__ void k_math(int which, int64_t n, const double *__restrict__ in,
+                       const double *__restrict__ in2, double *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = in[i];
+        double r;
+        switch (which) {
+        case 0: r = nxc_exp(v); break;
+        case 1: r = nxc_log(v); break;
+        case 2: r = nxc_cube(v); break;
+        case 3: r = __builtin_sqrt(v); break;
+        default: r = v / in2[i]; break;
+        }
+        out[i] = r;
+    }
+}

@@ -1,0 +1,106 @@
+// nxc_math.hpp -- device math of the nexoclom hot path on gfx950.
+//
+// The reference takes log(frac)/exp(.) once per RK step (particle_tracking/rk5.py:25,50), |r|**3
+// six times per step (particle_tracking/state.py:20) and errmax**-0.25 on a rejected adaptive step
+// (particle_tracking/Output.py:336).  NumPy's own SIMD pow/exp/log are only defined to 1 ulp (they
+// differ from glibc's on a few % of arguments), so instead of OCML's routines -- a third set of
+// 1-ulp answers -- these are built from IEEE-754 add/mul/div/fma/sqrt alone.  Compiled with
+// -ffp-contract=off every operation rounds once, so results are a pure function of the inputs
+// and can be checked bit for bit against a CPU evaluation of the same published algorithms
+// (tests/ do that; nothing here depends on the test code).
+//
+//   nxc_cube : r^3 as an error-free (double-double) product rounded once -> correctly rounded
+//   nxc_exp / nxc_log : table-free range reduction + minimax polynomial of Sun's fdlibm
+//                       (e_exp.c, e_log.c; < 1 ulp), coefficients from that publication
+//   nxc_pow_m025 : e^-0.25 = 1 / sqrt(sqrt(e))
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NXC_DEV __device__ __forceinline__
+
+NXC_DEV double nxc_cube(double r)
+{
+    double sq = r * r;
+    double sq_lo = __builtin_fma(r, r, -sq);
+    double cu = sq * r;
+    double cu_lo = __builtin_fma(sq, r, -cu);
+    return cu + (cu_lo + sq_lo * r);
+}
+
+NXC_DEV double nxc_exp(double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double INV_LN2 = 1.44269504088896338700e+00;
+    constexpr double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                     P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                     P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    double ax = __builtin_fabs(x), hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (ax > 0.34657359027997264) {
+        if (ax < 1.0397207708399179) {
+            k = x < 0 ? -1 : 1;
+        } else {
+            k = (int)(INV_LN2 * x + (x < 0 ? -0.5 : 0.5));
+        }
+        hi = x - (double)k * LN2_HI;
+        lo = (double)k * LN2_LO;
+        x = hi - lo;
+    } else if (ax < 3.725290298461914e-09) {
+        return 1.0 + x;
+    }
+    double t = x * x;
+    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021)
+        return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
+    return __longlong_as_double(__double_as_longlong(y) + ((long long)(k + 1000) << 52))
+           * 9.33263618503218878990e-302;
+}
+
+NXC_DEV double nxc_log(double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01,
+                     L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
+                     L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
+                     L7 = 1.479819860511658591e-01;
+    if (x != x) return x;
+    if (x == 0.0) return -__builtin_huge_val();
+    if (x < 0.0) return __builtin_nan("");
+    if (x == __builtin_huge_val()) return x;
+    int k = 0;
+    if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; k = -54; }
+    unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    int hx = (int)(u >> 32);
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int i = (hx + 0x95f64) & 0x100000;
+    u = ((unsigned long long)(unsigned)(hx | (i ^ 0x3ff00000)) << 32) | (u & 0xffffffffull);
+    x = __longlong_as_double((long long)u);
+    k += i >> 20;
+    double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return k == 0 ? 0.0 : dk * LN2_HI + dk * LN2_LO;
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * LN2_HI - ((R - dk * LN2_LO) - f);
+    }
+    double s = f / (2.0 + f), z = s * s, w = z * z;
+    double t1 = w * (L2 + w * (L4 + w * L6));
+    double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
+    double R = t2 + t1;
+    i = hx - 0x6147a;
+    int j = 0x6b851 - hx;
+    if ((i | j) > 0) {
+        double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R))
+                      : dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
+}
+
+NXC_DEV double nxc_pow_m025(double e) { return 1.0 / __builtin_sqrt(__builtin_sqrt(e)); }

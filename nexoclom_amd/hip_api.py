@@ -1,0 +1,300 @@
+"""ctypes binding of libnexoclom_hip.so (include/nexoclom_hip.h) -- the only door to the GPU.
+
+There is no CPU fallback: if the library is missing or no gfx950 device is visible, every
+entry point raises.  Arrays cross the boundary as C-contiguous float64 NumPy buffers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libnexoclom_hip.so')
+_dp = C.POINTER(C.c_double)
+NXC_MAX_LINES = 4
+NXC_RUN_IMAGE = 1
+NXC_UNIQUE_ID_BYTES = 128
+
+# every symbol include/nexoclom_hip.h declares
+EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_create',
+           'nxc_destroy', 'nxc_device_name', 'nxc_synchronize', 'nxc_set_forces',
+           'nxc_set_image', 'nxc_state', 'nxc_rk5_step', 'nxc_packets_upload', 'nxc_image_clear',
+           'nxc_image_download', 'nxc_counters_get', 'nxc_last_kernel_ms', 'nxc_integrate_const',
+           'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
+           'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
+           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch')
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class nxc_forces(C.Structure):
+    _fields_ = [('GM', C.c_double), ('vrplanet', C.c_double), ('photo', C.c_double),
+                ('lifetime', C.c_double), ('gravity', C.c_int32), ('radpres', C.c_int32),
+                ('has_photo', C.c_int32), ('reserved', C.c_int32), ('n_tab', C.c_int64),
+                ('v_tab', _dp), ('a_tab', _dp)]
+
+
+class nxc_image_desc(C.Structure):
+    _fields_ = [('M', C.c_double*9), ('vrplanet', C.c_double), ('apix_cm2', C.c_double),
+                ('quantity', C.c_int32), ('n_lines', C.c_int32), ('downcast_f32', C.c_int32),
+                ('reserved', C.c_int32), ('nx', C.c_int64), ('nz', C.c_int64),
+                ('xedges', _dp), ('zedges', _dp), ('line_n', C.c_int64*NXC_MAX_LINES),
+                ('line_v', _dp*NXC_MAX_LINES), ('line_g', _dp*NXC_MAX_LINES)]
+
+
+class nxc_counters(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in
+                ('particle_steps', 'samples', 'samples_binned', 'nonfinite', 'bad_step',
+                 'neg_frac', 'unfinished', 'reserved')]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library (building nothing); raises HipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(f'{LIB_PATH} not found: build it with `python -m nexoclom_amd.build` '
+                       '(there is no CPU fallback for the hot path)')
+    lib = C.CDLL(LIB_PATH)
+    lib.nxc_last_error_string.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)          # AttributeError here = ABI mismatch
+    if lib.nxc_abi_version() != 1:
+        raise HipError('libnexoclom_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count():
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.nxc_device_count(C.byref(n))
+    if rc != 0:
+        return 0
+    return n.value
+
+
+class Context:
+    """One device + stream + tables + resident packets/image (an ``nxc_handle``)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self._h = C.c_void_p()
+        self._check(self.lib.nxc_create(C.c_int(device), C.byref(self._h)))
+        self.device = device
+        self.n_packets = 0
+        self.image_shape = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.nxc_last_error_string()
+            raise HipError(f'nexoclom_hip error {rc}: {msg.decode() if msg else "?"}')
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.nxc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.nxc_device_name(self._h, buf, C.c_int(256)))
+        return buf.value.decode()
+
+    def synchronize(self):
+        self._check(self.lib.nxc_synchronize(self._h))
+
+    # -- set-up -----------------------------------------------------------------------------
+    def set_forces(self, GM, vrplanet, gravity=True, radpres=True, lifetime=0.0, photo=None,
+                   v_tab=None, a_tab=None):
+        f = nxc_forces()
+        f.GM, f.vrplanet = float(GM), float(vrplanet)
+        f.photo = 0.0 if photo is None else float(photo)
+        f.lifetime = float(lifetime)
+        f.gravity, f.radpres, f.has_photo = int(bool(gravity)), int(bool(radpres)), int(photo is not None)
+        if radpres:
+            v, a = _f64(v_tab), _f64(a_tab)
+            if v.shape != a.shape or v.ndim != 1:
+                raise ValueError('v_tab and a_tab must be 1-D arrays of equal length')
+            f.n_tab, f.v_tab, f.a_tab = len(v), _p(v), _p(a)
+        self._check(self.lib.nxc_set_forces(self._h, C.byref(f)))
+
+    def set_image(self, M, vrplanet, apix_cm2, quantity, xedges, zedges, g_tables=(),
+                  downcast_f32=False):
+        d = nxc_image_desc()
+        d.M = (C.c_double*9)(*np.asarray(M, dtype=float).reshape(9))
+        d.vrplanet, d.apix_cm2 = float(vrplanet), float(apix_cm2)
+        if quantity in ('column', 'density'):
+            d.quantity = 0
+        elif quantity in ('radiance', 'difrad'):
+            d.quantity = 1
+        else:
+            raise ValueError(f'{quantity} is invalid.')
+        d.downcast_f32 = int(bool(downcast_f32))
+        xe, ze = _f64(xedges), _f64(zedges)
+        d.nx, d.nz = len(xe)-1, len(ze)-1
+        d.xedges, d.zedges = _p(xe), _p(ze)
+        keep = [xe, ze]
+        if d.quantity == 1:
+            if len(g_tables) > NXC_MAX_LINES:
+                raise ValueError('too many emission lines')
+            d.n_lines = len(g_tables)
+            for k, (v, g) in enumerate(g_tables):
+                v, g = _f64(v), _f64(g)
+                keep += [v, g]
+                d.line_n[k], d.line_v[k], d.line_g[k] = len(v), _p(v), _p(g)
+        self._check(self.lib.nxc_set_image(self._h, C.byref(d)))
+        self.image_shape = (int(d.nx), int(d.nz))
+
+    # -- a-2 / a-1 --------------------------------------------------------------------------
+    def state(self, x, y, z, vy):
+        x, y, z, vy = map(_f64, (x, y, z, vy))
+        n = len(x)
+        out = [np.empty(n) for _ in range(4)]
+        self._check(self.lib.nxc_state(self._h, C.c_int64(n), _p(x), _p(y), _p(z), _p(vy),
+                                       *[_p(o) for o in out]))
+        return np.stack(out[:3], axis=1), out[3]
+
+    def rk5_step(self, X0, h, want_delta=False):
+        """X0 (N,8) as the reference's rk5 takes it; returns ((N,8) result, (N,8) delta|None)."""
+        X0 = np.asarray(X0, dtype=np.float64)
+        n = X0.shape[0]
+        soa = _f64(X0.T)
+        hh = _f64(np.broadcast_to(np.asarray(h, dtype=np.float64), (n,)))
+        out = np.empty((8, n))
+        delta = np.empty((8, n)) if want_delta else None
+        self._check(self.lib.nxc_rk5_step(self._h, C.c_int64(n), _p(soa), _p(hh), _p(out),
+                                          _p(delta) if want_delta else None))
+        return np.ascontiguousarray(out.T), (np.ascontiguousarray(delta.T) if want_delta else None)
+
+    # -- resident data ----------------------------------------------------------------------
+    def upload_packets(self, X0):
+        """X0 (N,8) row-major or an (8,N) SoA array flagged by ``soa=True`` via upload_soa."""
+        X0 = np.asarray(X0, dtype=np.float64)
+        return self.upload_soa(_f64(X0.T))
+
+    def upload_soa(self, soa):
+        soa = _f64(soa)
+        assert soa.ndim == 2 and soa.shape[0] == 8
+        self._check(self.lib.nxc_packets_upload(self._h, C.c_int64(soa.shape[1]), _p(soa)))
+        self.n_packets = soa.shape[1]
+
+    def image_clear(self):
+        self._check(self.lib.nxc_image_clear(self._h))
+
+    def image_download(self):
+        nx, nz = self.image_shape
+        image = np.empty((nx, nz))
+        counts = np.empty((nx, nz), dtype=np.uint64)
+        self._check(self.lib.nxc_image_download(self._h, _p(image),
+                                                counts.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return image, counts
+
+    def counters(self):
+        c = nxc_counters()
+        self._check(self.lib.nxc_counters_get(self._h, C.byref(c)))
+        return {k: int(getattr(c, k)) for k, _ in nxc_counters._fields_ if k != 'reserved'}
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(self.lib.nxc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- a-3 / a-4 --------------------------------------------------------------------------
+    def integrate_const(self, step, n_iter, outeredge, image=False, nrec=0, want_final=False,
+                        want_steps=False):
+        """Constant-step driver over the resident packets.
+
+        nrec > 0 returns the trajectory as an (8, nrec, N) array (lock-step kernel); otherwise the
+        persistent lane-refill kernel runs.  Returns dict(traj, final (N,8), steps)."""
+        n = self.n_packets
+        traj = np.empty((8, nrec, n)) if nrec else None
+        final = np.empty((8, n)) if want_final else None
+        steps = np.empty(n, dtype=np.int64) if want_steps else None
+        self._check(self.lib.nxc_integrate_const(
+            self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
+            C.c_uint32(NXC_RUN_IMAGE if image else 0), _p(traj) if nrec else None,
+            C.c_int64(nrec), _p(final) if want_final else None,
+            steps.ctypes.data_as(C.POINTER(C.c_int64)) if want_steps else None))
+        return dict(traj=traj, final=None if final is None else np.ascontiguousarray(final.T),
+                    steps=steps)
+
+    def integrate_const_async(self, step, n_iter, outeredge, image=True):
+        self._check(self.lib.nxc_integrate_const_async(
+            self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
+            C.c_uint32(NXC_RUN_IMAGE if image else 0)))
+
+    def integrate_var(self, resolution, outeredge, max_steps=10**7):
+        n = self.n_packets
+        final = np.empty((8, n))
+        hs = np.empty(n)
+        self._check(self.lib.nxc_integrate_var(self._h, C.c_double(resolution),
+                                               C.c_double(outeredge), C.c_int64(max_steps),
+                                               _p(final), _p(hs)))
+        return np.ascontiguousarray(final.T), hs
+
+    # -- a-6..a-8 ---------------------------------------------------------------------------
+    def image_accumulate(self, x, y, z, vy, frac):
+        x, y, z, vy, frac = map(_f64, (x, y, z, vy, frac))
+        self._check(self.lib.nxc_image_accumulate(self._h, C.c_int64(len(x)), _p(x), _p(y), _p(z),
+                                                  _p(vy), _p(frac)))
+
+    # -- RCCL -------------------------------------------------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_uint8*NXC_UNIQUE_ID_BYTES)()
+        self._check(self.lib.nxc_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = (C.c_uint8*NXC_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self.lib.nxc_comm_init(self._h, buf, C.c_int(rank), C.c_int(nranks)))
+
+    def comm_destroy(self):
+        self._check(self.lib.nxc_comm_destroy(self._h))
+
+    def image_allreduce(self):
+        self._check(self.lib.nxc_image_allreduce(self._h))
+
+    def allreduce_max(self, value):
+        v = C.c_double(value)
+        self._check(self.lib.nxc_allreduce_max_f64(self._h, C.byref(v)))
+        return float(v.value)
+
+    def barrier(self):
+        self._check(self.lib.nxc_barrier(self._h))
+
+    # -- diagnostics ------------------------------------------------------------------------
+    def math(self, which, x, y=None):
+        code = {'exp': 0, 'log': 1, 'cube': 2, 'sqrt': 3, 'div': 4}[which]
+        x = _f64(x)
+        out = np.empty_like(x)
+        y2 = _f64(y) if y is not None else None
+        self._check(self.lib.nxc_math_batch(self._h, C.c_int(code), C.c_int64(len(x)), _p(x),
+                                            _p(y2) if y2 is not None else None, _p(out)))
+        return out

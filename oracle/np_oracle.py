@@ -1,0 +1,339 @@
+"""NumPy oracle for the nexoclom particle_tracking + image hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``nexoclom_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and there
+only as the checker / the timed CPU baseline.
+
+This is a CPU re-statement, in NumPy, of the reference's algorithm with the reference's exact
+floating-point operation order, so that on one machine it reproduces the reference bit for bit
+(pinned by ``oracle/make_golden.py``, which loads the reference's own ``rk5.py`` / ``state.py`` /
+``histogram.py`` / ``rotation_matrix.py`` by path and compares).  Each function cites the
+reference lines it follows (paths under /root/reference/nexoclom/).
+
+Packet state columns, as in the reference: [t_remaining, x, y, z, vx, vy, vz, frac].
+Lengths in planet radii R, times in s.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+# --- Dormand-Prince tableau: particle_tracking/rk5.py:5-18 --------------------------------------
+C_NODES = np.array([0, 0.2, 0.3, 0.8, 8./9., 1., 1.])
+B5 = np.array([35./384., 0., 500./1113., 125./192., -2187./6784., 11./84., 0.])
+B4 = np.array([5179./57600., 0., 7571./16695., 393./640., -92097./339200., 187./2100., 1./40.])
+B_DIFF = B5 - B4
+A_TAB = np.zeros((7, 7))
+A_TAB[1, 0] = 0.2
+A_TAB[2, :2] = [3./40., 9./40.]
+A_TAB[3, :3] = [44./45., -56./15., 32./9.]
+A_TAB[4, :4] = [19372./6561., -25360./2187., 64448./6561., -212./729.]
+A_TAB[5, :5] = [9017./3168., -355./33., 46732./5247., 49./176., -5103./18656.]
+A_TAB[6, :] = B5
+
+
+@dataclass
+class Forces:
+    """Scalars and tables consumed by state(): what Output.__init__ (particle_tracking/
+    Output.py:105-128) hangs on the ``output`` object."""
+    GM: float                       # R^3/s^2, negative (solarsystem/SSObject.py:53)
+    vrplanet: float                 # R/s
+    gravity: bool = True
+    radpres: bool = True
+    lifetime: float = 0.            # s; >0 => constant loss rate 1/lifetime (state.py:44-46)
+    photo: Optional[float] = None   # 1/s (loss_info.photo, state.py:48-52); None => no loss
+    v_tab: np.ndarray = field(default_factory=lambda: np.array([0., 1.]))   # R/s, ascending
+    a_tab: np.ndarray = field(default_factory=lambda: np.array([0., 0.]))   # R/s^2
+
+
+def _norm3(a, b, c):
+    # np.linalg.norm(x[:,1:4], axis=1) == sqrt(add.reduce(x*x, axis=1)): ((a*a + b*b) + c*c)
+    return np.sqrt((a*a + b*b) + c*c)
+
+
+def _out_of_shadow(xs, ys, zs):
+    # state.py:28-29 / :50-51: rho = norm(x[:, [1, 3]]); (rho > 1) | (y < 0)
+    rho = np.sqrt(xs*xs + zs*zs)
+    return (rho > 1) | (ys < 0)
+
+
+def state(x, f: Forces):
+    """Acceleration (N,3) and loss rate (N,) of packets x (N,8).  particle_tracking/state.py:17-74."""
+    n = x.shape[0]
+    px, py, pz = x[:, 1], x[:, 2], x[:, 3]
+    if f.gravity:                                        # state.py:19-21
+        r3 = _norm3(px, py, pz)**3
+        ax, ay, az = f.GM*px/r3, f.GM*py/r3, f.GM*pz/r3
+    else:                                                # state.py:22-23
+        ax, ay, az = np.zeros(n), np.zeros(n), np.zeros(n)
+
+    if f.radpres:                                        # state.py:27-36
+        oos = _out_of_shadow(px, py, pz)
+        vv = x[:, 5] + f.vrplanet
+        arad_y = np.interp(vv, f.v_tab, f.a_tab) * oos
+    else:
+        arad_y = np.zeros(n)
+    accel = np.empty((n, 3))                             # state.py:41: agrav + arad
+    accel[:, 0] = ax + 0.0
+    accel[:, 1] = ay + arad_y
+    accel[:, 2] = az + 0.0
+
+    if f.lifetime > 0:                                   # state.py:44-46
+        ioniz = np.ones(n)/f.lifetime
+    elif f.photo is not None:                            # state.py:48-52
+        ioniz = f.photo * _out_of_shadow(px, py, pz)
+    else:                                                # state.py:53-54
+        ioniz = np.zeros(n)
+    return accel, ioniz
+
+
+def rk5(f: Forces, X0, h, want_delta=False):
+    """One Dormand-Prince step of size h (N,) for packets X0 (N,8).  particle_tracking/rk5.py:21-54.
+
+    frac is integrated as log(frac) (rk5.py:25,35,50).  Each stage is accumulated from zero in
+    the order i = 0..n with terms (h*a[n+1,i])*k_i and the initial state added LAST (rk5.py:32-36).
+    delta (variable-step mode) sums B_DIFF over the first SIX stages only (rk5.py:40-44).
+    """
+    n = X0.shape[0]
+    h = np.broadcast_to(np.asarray(h, dtype=float), (n,))
+    y0 = X0.copy()
+    y0[:, 7] = np.log(y0[:, 7])
+    stage = y0
+    kv, ka, kl = [], [], []          # stage velocities, accelerations, loss rates
+    for s in range(6):
+        acc, ion = state(stage, f)
+        kv.append(stage[:, 4:7].copy())
+        ka.append(acc)
+        kl.append(ion)
+        nxt = np.zeros_like(y0)
+        nxt[:, 0] = -h*C_NODES[s+1]
+        for i in range(s+1):
+            w = h*A_TAB[s+1, i]
+            nxt[:, 1:4] += w[:, None]*kv[i]
+            nxt[:, 4:7] += w[:, None]*ka[i]
+            nxt[:, 7] -= w*kl[i]
+        nxt += y0
+        stage = nxt
+    delta = None
+    if want_delta:                                       # rk5.py:38-46
+        delta = np.zeros_like(X0)
+        for i in range(6):
+            delta[:, 1:4] += B_DIFF[i]*kv[i]
+            delta[:, 4:7] += B_DIFF[i]*ka[i]
+            delta[:, 7] += B_DIFF[i]*kl[i]
+        delta = np.abs(h[:, None]*delta)
+    result = stage
+    result[:, 7] = np.exp(result[:, 7])
+    return result, delta
+
+
+def n_output_steps(endtime, step):
+    """nsteps of the constant-step driver (Output.py:375) and the number of loop iterations the
+    ``while curtime > 0`` loop (Output.py:384,431) performs."""
+    nsteps = int(np.ceil(endtime/step + 1))
+    curtime, iters = float(endtime), 0
+    while curtime > 0:
+        iters += 1
+        curtime -= step
+    return nsteps, iters
+
+
+def apply_fate(Xn, outeredge, r_is_squared=False):
+    """Surface impact / escape / vanishing tests applied after a step (stickcoef == 1).
+
+    Constant driver Output.py:395-416 (r = |x|); the variable driver uses r^2 for BOTH tests
+    (Output.py:308-324, including the r^2-vs-outeredge comparison at :318)."""
+    r2 = (Xn[:, 1]*Xn[:, 1] + Xn[:, 2]*Xn[:, 2]) + Xn[:, 3]*Xn[:, 3]
+    rr = r2 if r_is_squared else np.sqrt(r2)
+    if r_is_squared:
+        Xn[rr < 1, 7] = 0.
+    else:
+        Xn[(rr - 1.) < 0, 7] = 0.
+    Xn[rr > outeredge, 7] = 0.
+    Xn[Xn[:, 7] < 1e-10, 7] = 0.
+    Xn[Xn[:, 7] == 0, 0] = 0.
+    return Xn
+
+
+def constant_step_driver(f: Forces, X0, endtime, step, outeredge, progress=False, rk5_fn=None):
+    """Constant-step trajectory integration.  particle_tracking/Output.py:368-431.
+
+    Returns results (N,8,nsteps), lossfrac (N,nsteps) and the number of particle-steps taken
+    (sum over iterations of active packets, the BASELINE metric's unit of work).  lossfrac starts
+    from zero here; the reference's is uninitialised memory (Output.py:378).  ``rk5_fn`` lets
+    make_golden.py drive this loop around the reference's own imported rk5.
+    """
+    rk5_fn = rk5_fn or (lambda X, h: rk5(f, X, h))
+    n = X0.shape[0]
+    nsteps, _ = n_output_steps(endtime, step)
+    results = np.zeros((n, 8, nsteps))
+    results[:, :, 0] = X0
+    lossfrac = np.zeros((n, nsteps))
+    curtime, ct, work = float(endtime), 1, 0
+    alive = results[:, 7, 0] > 0
+    while curtime > 0 and alive.any():
+        todo = results[alive, :, ct-1]
+        hh = np.zeros(todo.shape[0]) + step
+        Xn, _ = rk5_fn(todo, hh)
+        work += todo.shape[0]
+        Xn = apply_fate(Xn, outeredge)
+        results[alive, :, ct] = Xn
+        lossfrac[alive, ct] = (lossfrac[alive, ct-1] + results[alive, 7, ct-1]
+                               - results[alive, 7, ct])
+        alive = results[:, 7, ct] > 0
+        if progress and ct % 100 == 0:
+            print(ct, curtime, int(alive.sum()))
+        ct += 1
+        curtime -= step
+    return results, lossfrac, work
+
+
+def variable_step_driver(f: Forces, X, resolution, outeredge, max_iter=10**7, rk5_fn=None):
+    """Adaptive-step integration to the final snapshot.  particle_tracking/Output.py:221-359.
+
+    X is (N,8); returns the final (N,8) array, final step sizes and the number of rk5
+    particle-steps attempted.  Tolerances: x,frac -> resolution, v -> 0.1*resolution
+    (Output.py:235-238); errmax is the max over the 8 columns of delta/scale with the time column
+    0 (:271-281); quirks kept: r^2 compared with 1 and with outeredge (:308-318).
+    """
+    safety, shrink = 0.95, -0.25
+    rk5_fn = rk5_fn or (lambda X_, h_: rk5(f, X_, h_, want_delta=True))
+    rest = resx = resf = resolution
+    resv = 0.1*resolution
+    X = X.copy()
+    n = X.shape[0]
+    step_size = np.zeros(n) + 1000.
+    work = 0
+    more = (X[:, 0] > rest) & (X[:, 7] > 0.)
+    it = 0
+    while more.any():
+        idx = np.nonzero(more)[0]
+        todo = X[idx]
+        hcur = np.minimum(todo[:, 0], step_size[idx])
+        assert np.all(hcur > 0), 'Bad step size'
+        Xn, delta = rk5_fn(todo, hcur)
+        work += idx.size
+        scalex = resx + np.abs(Xn[:, 1:4])*resx
+        scalev = resv + np.abs(Xn[:, 4:7])*resv
+        scalef = resf + np.abs(Xn[:, 7])*resf
+        delta[:, 1:4] /= scalex
+        delta[:, 4:7] /= scalev
+        delta[:, 7] /= scalef
+        errmax = np.fmax.reduce(delta, axis=1)   # pandas row.max() skips NaN (Output.py:281)
+        assert np.all(np.isfinite(errmax)), '\n\tInfinite values of emax'
+        assert not np.any((Xn[:, 7] < 0) & (errmax < 1)), \
+            'Found new values of frac that are negative'
+        errmax[(Xn[:, 7] - todo[:, 7] > scalef) & (errmax > 1)] = 1.1
+        # "No error" steps get errmax = 1, i.e. they are REJECTED and retried with a step
+        # 0.95*10 times larger (Output.py:294-300: b = errmax >= 1.0).
+        noerr = errmax < 1e-7
+        errmax[noerr] = 1
+        hbad = hcur.copy()
+        hbad[noerr] *= 10
+        good = errmax < 1.0
+        bad = ~good
+        if good.any():
+            # The grown step (safety*h*errmax**grow, Output.py:304-305) is computed by the
+            # reference but never stored: only the 8 state columns are written back (:327), so
+            # the stored step size changes in the rejected branch alone.
+            Xg = apply_fate(Xn[good], outeredge, r_is_squared=True)
+            X[idx[good]] = Xg
+        if bad.any():
+            old_ = hbad[bad]
+            step_ = safety * old_ * errmax[bad]**shrink
+            assert np.all(np.isfinite(step_)), '\n\tInfinite values of step_size'
+            step_size[idx[bad]] = np.maximum(step_, 0.1*old_)
+        more = (X[:, 0] > rest) & (X[:, 7] > 0.)
+        it += 1
+        if it > max_iter:
+            raise RuntimeError('variable_step_driver did not converge')
+    return X, step_size, work
+
+
+# --- image pipeline ------------------------------------------------------------------------------
+
+def rotation_matrix(theta, axis):
+    """Rotation by theta about axis.  math/rotation_matrix.py:5-14."""
+    u = axis/np.linalg.norm(axis)
+    lx, ly, lz = u[0], u[1], u[2]
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[lx**2+(1-lx**2)*c, lx*ly*(1-c)+lz*s, lx*lz*(1-c)-ly*s],
+                     [lx*ly*(1-c)-lz*s, ly**2+(1-ly**2)*c, ly*lz*(1-c)+lx*s],
+                     [lx*lz*(1-c)+ly*s, ly*lz*(1-c)-lx*s, lz**2+(1-lz**2)*c]])
+
+
+def image_rotation(subobslongitude, subobslatitude):
+    """Sun-frame -> observer-frame rotation.  data_simulation/ModelImage.py:367-384."""
+    slong, slat = subobslongitude, subobslatitude
+    pSun = np.array([0., -1., 0.])
+    pObs = np.array([np.sin(slong)*np.cos(slat), -np.cos(slong)*np.cos(slat), np.sin(slat)])
+    if np.array_equal(pSun, pObs):
+        return np.eye(3)
+    costh = np.dot(pSun, pObs)/np.linalg.norm(pSun)/np.linalg.norm(pObs)
+    theta = np.arccos(np.clip(costh, -1, 1))
+    return rotation_matrix(theta, np.cross(pSun, pObs))
+
+
+def packet_weights(frac, radvel_sun, out_of_shadow, quantity, g_tables=()):
+    """Per-sample weight.  data_simulation/ModelResult.py:140-170.
+
+    column/density: frac.  radiance/difrad: frac * out_of_shadow * sum_lines interp(radvel_sun;
+    v_line, g_line) / 1e6, g_tables = [(v [R/s], g [1/s]), ...]."""
+    if quantity in ('column', 'density'):
+        return frac.copy()
+    if quantity in ('radiance', 'difrad'):
+        gg = np.zeros(len(frac))
+        for v_tab, g_tab in g_tables:
+            gg += np.interp(radvel_sun, v_tab, g_tab)
+        return frac*out_of_shadow*gg/1e6
+    raise ValueError(f'{quantity} is invalid.')
+
+
+def create_image(x, y, z, vy, frac, vrplanet, M, quantity, g_tables, dims, xrange_, zrange_,
+                 apix_cm2, matmul=True):
+    """Weighted image + packet-count image of samples (x,y,z,vy,frac).
+
+    data_simulation/ModelImage.py:242-269 with math/histogram.py:32-36: rotate, occultation mask
+    into frac, sunlight mask, weights / Apix, np.histogram2d over (x_obs, z_obs).  ``matmul=False``
+    evaluates the 3x3 rotation with explicit multiply-adds in the order the HIP kernel uses
+    ((m0*x + m1*y) + m2*z) instead of BLAS dgemm; the two differ by <= 1 ulp per coordinate.
+    """
+    radvel_sun = vy + vrplanet
+    pts_sun = np.stack([x, y, z], axis=1)
+    if matmul:
+        pts_obs = np.array(np.matmul(M, pts_sun.transpose()).transpose())
+    else:
+        pts_obs = np.empty_like(pts_sun)
+        for r in range(3):
+            pts_obs[:, r] = (M[r, 0]*x + M[r, 1]*y) + M[r, 2]*z
+    rho_obs = np.linalg.norm(pts_obs[:, [0, 2]], axis=1)
+    inview = (rho_obs > 1) | (pts_obs[:, 1] < 0)
+    frac = frac*inview
+    rho_sun = np.linalg.norm(pts_sun[:, [0, 2]], axis=1)
+    out_of_shadow = (rho_sun > 1) | (pts_sun[:, 1] < 0)
+    weight = packet_weights(frac, radvel_sun, out_of_shadow, quantity, g_tables)
+    assert np.all(np.isfinite(weight)), 'Non-finite weights'
+    weight = weight/apix_cm2
+    rng = [list(xrange_), list(zrange_)]
+    image, ex, ez = np.histogram2d(pts_obs[:, 0], pts_obs[:, 2], weights=weight, bins=dims,
+                                   range=rng)
+    counts, _, _ = np.histogram2d(pts_obs[:, 0], pts_obs[:, 2], bins=dims, range=rng)
+    return image, counts, ex, ez
+
+
+def samples_from_results(results, compress=True, downcast=False):
+    """Flatten a constant-driver results array (N,8,nsteps) into the sample columns the image
+    code reads from Output.X (Output.py:435-447), dropping frac == 0 rows when ``compress``
+    (Output.py:523-524) and optionally applying the float32 round trip of save()/restore()
+    (Output.py:528-543,555-570)."""
+    cols = {}
+    for name, k in (('x', 1), ('y', 2), ('z', 3), ('vy', 5), ('frac', 7)):
+        cols[name] = results[:, k, :].reshape(-1)
+    keep = cols['frac'] > 0 if compress else np.ones(cols['frac'].shape, bool)
+    out = {}
+    for name, v in cols.items():
+        v = v[keep]
+        if downcast:
+            v = v.astype(np.float32).astype(np.float64)
+        out[name] = v
+    return out

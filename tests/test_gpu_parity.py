@@ -1,0 +1,158 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracles.
+
+Contract (DESIGN.md "Parity"):
+  * HIP vs C oracle: BIT-EXACT for every state column and every integer (steps, counts); the
+    weighted image differs only by fp64 atomic summation order (rtol 1e-12).
+  * HIP vs NumPy oracle (= the reference's arithmetic, pinned by tests/golden): rtol 1e-12 per
+    step; the only differences are NumPy's own 1-ulp pow/exp/log kernels.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_math_is_ieee_exact(ctx, coracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(1e-3, 1e3, 400000)
+    y = rng.uniform(1e-3, 1e3, 400000)
+    assert np.array_equal(ctx.math('sqrt', x), np.sqrt(x))
+    assert np.array_equal(ctx.math('div', x, y), x/y)
+    r = rng.uniform(0.5, 40, 400000)
+    assert np.array_equal(ctx.math('cube', r), coracle.math('cube', r))
+    e = -rng.uniform(0, 40, 400000)
+    assert np.array_equal(ctx.math('exp', e), coracle.math('exp', e))
+    fr = np.concatenate([rng.uniform(1e-10, 1, 400000), 10**rng.uniform(-12, 3, 1000)])
+    assert np.array_equal(ctx.math('log', fr), coracle.math('log', fr))
+
+
+@pytest.mark.parametrize('gravity,radpres,lifetime', [
+    (True, True, 0.0), (True, False, 0.0), (False, True, 0.0), (True, True, 3600.0),
+    (True, True, -7200.0), (False, False, 0.0)])
+def test_state_matches_oracles(ctx, coracle, gravity, radpres, lifetime):
+    f = H.mercury_forces('Na', 1.3, gravity, radpres, lifetime)
+    H.set_ctx_forces(ctx, f)
+    X = H.random_cloud(4096, 11)
+    a_g, i_g = ctx.state(X[:, 1], X[:, 2], X[:, 3], X[:, 5])
+    a_c, i_c = coracle.state(f, X[:, 1], X[:, 2], X[:, 3], X[:, 5])
+    assert np.array_equal(a_g, a_c) and np.array_equal(i_g, i_c)
+    a_n, i_n = O.state(X, f)
+    assert np.array_equal(i_g, i_n)
+    np.testing.assert_allclose(a_g, a_n, rtol=2e-15, atol=1e-22)
+
+
+@pytest.mark.parametrize('species,taa', [('Na', 1.3), ('Ca', 0.0), ('Mg', 3.14)])
+def test_rk5_step_matches_oracles(ctx, coracle, species, taa):
+    f = H.mercury_forces(species, taa)
+    H.set_ctx_forces(ctx, f)
+    X = H.random_cloud(8192, 5)
+    h = np.random.default_rng(2).uniform(1, 120, len(X))
+    r_g, d_g = ctx.rk5_step(X, h, want_delta=True)
+    r_c, d_c = coracle.rk5(f, X, h, want_delta=True)
+    assert np.array_equal(r_g, r_c)
+    assert np.array_equal(d_g, d_c)
+    r_n, d_n = O.rk5(f, X, h, want_delta=True)
+    np.testing.assert_allclose(r_g, r_n, rtol=1e-13, atol=1e-18)
+    r_g2, none = ctx.rk5_step(X, 30.0)
+    assert none is None
+    r_c2, _ = coracle.rk5(f, X, 30.0)
+    assert np.array_equal(r_g2, r_c2)
+
+
+def _const_case(ctx, coracle, f, n, seed, endtime, step, outeredge, image=None):
+    H.set_ctx_forces(ctx, f)
+    X0 = H.sample_x0(n, seed, endtime)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    ctx.upload_packets(X0)
+    return X0, nsteps, n_iter
+
+
+def test_const_driver_trajectory_bit_exact(ctx, coracle):
+    f = H.mercury_forces('Na', 1.3)
+    endtime, step, edge = 6000.0, 30.0, 25.0
+    X0, nsteps, n_iter = _const_case(ctx, coracle, f, 3000, 1234, endtime, step, edge)
+    g = ctx.integrate_const(step, n_iter, edge, nrec=nsteps, want_final=True, want_steps=True)
+    c = coracle.integrate_const(f, X0, step, n_iter, edge, nrec=nsteps, threads=4)
+    assert np.array_equal(g['traj'], c['traj'])
+    assert np.array_equal(g['steps'], c['steps'])
+    assert np.array_equal(g['final'], c['final'])
+    assert ctx.counters()['particle_steps'] == c['work']
+    # and against the NumPy restatement of the reference driver
+    res, _, work = O.constant_step_driver(f, X0[:400], endtime, step, edge)
+    np.testing.assert_allclose(g['traj'][:, :, :400].transpose(2, 0, 1), res, rtol=1e-9,
+                               atol=1e-12)
+
+
+def test_const_driver_lane_refill_bit_exact(ctx, coracle):
+    """Persistent lane-refill kernel == lock-step kernel == C oracle, packet for packet."""
+    f = H.mercury_forces('Na', 1.3)
+    endtime, step, edge = 50000.0, 30.0, 25.0
+    X0, nsteps, n_iter = _const_case(ctx, coracle, f, 20000, 99, endtime, step, edge)
+    g = ctx.integrate_const(step, n_iter, edge, want_final=True, want_steps=True)
+    c = coracle.integrate_const(f, X0, step, n_iter, edge, threads=8)
+    assert np.array_equal(g['steps'], c['steps'])
+    assert np.array_equal(g['final'], c['final'])
+    assert ctx.counters()['particle_steps'] == c['work']
+
+
+@pytest.mark.parametrize('quantity,downcast', [('radiance', False), ('column', False),
+                                               ('radiance', True)])
+def test_fused_image_matches_oracle(ctx, coracle, quantity, downcast):
+    f = H.mercury_forces('Na', 1.3)
+    endtime, step, edge = 50000.0, 30.0, 25.0
+    X0, nsteps, n_iter = _const_case(ctx, coracle, f, 20000, 7, endtime, step, edge)
+    im = H.image_setup(f, quantity, dims=(128, 96), width=(8., 6.), sublon=0.4, sublat=1.1)
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], quantity, im['xedges'], im['zedges'],
+                  im['g_tables'], downcast_f32=downcast)
+    ctx.integrate_const(step, n_iter, edge, image=True)
+    image, counts = ctx.image_download()
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], quantity, im['g_tables'],
+                              im['xedges'], im['zedges'], downcast=downcast)
+    c = coracle.integrate_const(f, X0, step, n_iter, edge, img=desc, threads=8)
+    assert np.array_equal(counts, c['counts'])
+    np.testing.assert_allclose(image, c['image'], rtol=1e-11, atol=0)
+    ctr = ctx.counters()
+    assert ctr['samples_binned'] == int(counts.sum())
+    assert ctr['nonfinite'] == 0
+
+
+def test_image_kernel_matches_numpy_histogram(ctx, coracle):
+    f = H.mercury_forces('Na', 1.3)
+    rng = np.random.default_rng(5)
+    p = 300000
+    X = H.random_cloud(p, 21)
+    x, y, z, vy, frac = X[:, 1], X[:, 2], X[:, 3], X[:, 5], X[:, 7]
+    im = H.image_setup(f, 'radiance', dims=(512, 512))
+    # samples exactly on edges, on the right-most edge and outside
+    x[:513] = im['xedges']; z[:513] = im['zedges'][::-1]
+    x[600:610] = 4.0; z[600:610] = rng.uniform(-4, 4, 10)
+    x[700:710] = 4.0000001
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'])
+    ctx.image_accumulate(x, y, z, vy, frac)
+    image, counts = ctx.image_download()
+    ref_img, ref_cnt, _, _ = O.create_image(x, y, z, vy, frac, f.vrplanet, im['M'], 'radiance',
+                                            im['g_tables'], im['dims'], im['xrange'],
+                                            im['zrange'], im['apix'], matmul=False)
+    assert np.array_equal(counts, ref_cnt.astype(np.uint64))
+    np.testing.assert_allclose(image, ref_img, rtol=1e-12, atol=0)
+
+
+def test_variable_driver_bit_exact(ctx, coracle):
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    n, endtime = 5000, 20000.0
+    X0 = H.sample_x0(n, 4321, endtime)
+    X0[:, 0] = np.random.default_rng(8).random(n)*endtime
+    ctx.upload_packets(X0)
+    g_final, g_hs = ctx.integrate_var(1e-4, 25.0)
+    c_final, c_hs, work, bad = coracle.integrate_var(f, X0, 1e-4, 25.0)
+    assert bad == 0
+    assert np.array_equal(g_final, c_final)
+    assert np.array_equal(g_hs, c_hs)
+    ctr = ctx.counters()
+    assert ctr['particle_steps'] == work
+    assert ctr['bad_step'] == ctr['nonfinite'] == ctr['neg_frac'] == ctr['unfinished'] == 0
