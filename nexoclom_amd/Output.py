@@ -1,0 +1,304 @@
+"""Output: packet trajectories, integrated on the GPU.
+
+Drop-in for the reference's particle_tracking/Output.py:23-455 on the particle-tracking path:
+same constructor signature ``Output(inputs, npackets, compress=True, run_model=True, seed=None)``,
+same attributes (X0, X, npackets, totalsource, nsteps, unit, GM, aplanet, vrplanet, radpres,
+loss_info, randgen, compress, inputs, planet) and the same column order of ``X``.  What differs:
+
+* ``constant_step_size_driver`` / ``variable_step_size_driver`` call the HIP kernels through the
+  C ABI (nexoclom_amd.hip_api) instead of looping over NumPy rk5 steps.  There is NO CPU
+  integrator in this package: without the HIP library or a GPU these methods raise.
+* ``save()`` writes an .npz next to an in-memory catalogue instead of PostgreSQL + pickle
+  (persistence is out of scope), but applies the same ``compress`` row filter
+  and float32 down-cast (Output.py:522-543) so that what ModelImage later reads is what the
+  reference would read.
+* keyword-only extras: ``device`` (GPU index), ``integrate`` (False: set up and sample X0 only),
+  ``keep_trajectory`` (False: constant-step runs never materialise the (N, 8, nsteps) tensor --
+  used by the fused integrate+image path), ``context`` (share one hip_api.Context).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+
+from .atomicdata import LossInfo, RadPresConst
+from .solarsystem import planet_dist
+from .source_distribution import (angular_distribution, speed_distribution,
+                                  surface_distribution)
+from .units import Quantity, register_unit
+
+STATE_COLS = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']
+
+
+def n_output_steps(endtime, step):
+    """nsteps (Output.py:375) and the number of iterations of the ``while curtime > 0`` loop
+    (Output.py:384,431), evaluated with the same float arithmetic."""
+    nsteps = int(np.ceil(endtime/step + 1))
+    curtime, iters = float(endtime), 0
+    while curtime > 0:
+        iters += 1
+        curtime -= step
+    return nsteps, min(iters, nsteps-1)
+
+
+class Output:
+    def __init__(self, inputs, npackets, compress=True, run_model=True, seed=None, *,
+                 device=0, integrate=True, keep_trajectory=True, context=None, save=True):
+        self.inputs = inputs
+        self.planet = inputs.geometry.planet
+        self._ctx = context
+        self._device = device
+        self.filename = None
+        self.idnum = None
+        if run_model:
+            self.randgen = np.random.default_rng(seed=seed)
+            assert self.inputs.geometry.type != 'geometry with time', (
+                'Initialization with time stamp not implemented yet.')
+            self.compress = compress
+            npackets = int(npackets)
+
+            # length unit = planet radius (Output.py:102)
+            self.unit = 'R_' + self.planet.object
+            self.unit_km = self.planet.radius.value
+            register_unit(self.unit, 'length', self.unit_km*1e3)
+            # GM in R^3/s^2, negative (Output.py:105; SSObject.py:53)
+            self.GM = self.planet.GM.value / (self.unit_km*1e3)**3
+
+            r, v_r = planet_dist(self.planet, inputs.geometry.taa)      # Output.py:108-110
+            self.aplanet = r.value
+            self.vrplanet = v_r.value / self.unit_km
+
+            if inputs.options.lifetime.value <= 0:                      # Output.py:113-118
+                self.loss_info = LossInfo(inputs.options.species, inputs.options.lifetime,
+                                          self.aplanet)
+            else:
+                self.loss_info = None
+
+            if inputs.forces.radpres:                                   # Output.py:121-128
+                radpres = RadPresConst(inputs.options.species, self.aplanet)
+                radpres.velocity = radpres.velocity / self.unit_km
+                radpres.accel = radpres.accel / self.unit_km
+                self.radpres = radpres
+            else:
+                self.radpres = None
+
+            sint = inputs.surfaceinteraction
+            if ('stickcoef' not in sint.__dict__) or (sint.stickcoef != 1):
+                raise NotImplementedError(
+                    'surface re-emission (stickcoef != 1, bouncepackets.py) is outside the '
+                    'GPU hot path of this round (SURVEY.md section 8f rank 2)')
+
+            if inputs.options.step_size != 0:                           # Output.py:136-141
+                time = np.ones(npackets) * inputs.options.endtime.value
+            else:
+                time = self.randgen.random(npackets) * inputs.options.endtime.value
+
+            self.X0 = pd.DataFrame()
+            self.X0['time'] = time
+            self.X0['frac'] = np.ones(npackets)
+            self.npackets = npackets
+            self.totalsource = self.X0['frac'].sum()
+
+            if self.planet.moons is not None:                           # Output.py:153-155
+                assert False, 'Not set up'
+
+            if inputs.spatialdist.type in ('uniform', 'surface map', 'surface spot'):
+                surface_distribution(self)
+            else:
+                assert 0, 'Not a valid spatial distribution type'
+            speed_distribution(self)
+            angular_distribution(self)
+
+            if inputs.geometry.planet.object != inputs.geometry.startpoint:
+                assert 0, 'Not set up yet'
+
+            cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac', 'v',
+                    'longitude', 'latitude', 'local_time', 'altitude', 'azimuth']
+            self.X0 = self.X0[cols]
+            self.nsteps = None
+            self.X = pd.DataFrame()
+            self.counters = {}
+
+            if integrate:
+                if inputs.options.step_size == 0:
+                    print('Running variable step size integrator.')
+                    self.X = self.X0.drop(['longitude', 'latitude', 'local_time'], axis=1)
+                    self.X['lossfrac'] = np.zeros(npackets)
+                    self.variable_step_size_driver()
+                else:
+                    print('Running constant step size integrator.')
+                    self.constant_step_size_driver(keep_trajectory=keep_trajectory)
+        else:
+            print('Not running anything')
+            self.compress = False
+            self.X0 = pd.DataFrame()
+            self.X = pd.DataFrame()
+            self.npackets = npackets
+            self.totalsource = npackets
+        if save and (not run_model or integrate):
+            self.save()
+
+    def __len__(self):
+        return self.npackets
+
+    def __str__(self):
+        return (f'Contents of output:\n\tPlanet = {self.planet.object}\n'
+                f'\ta_planet = {self.aplanet}\n\tvr_planet = {self.vrplanet}\n'
+                f'\tNumber of Packets: {self.npackets}')
+
+    # ---- GPU plumbing ---------------------------------------------------------------------
+    def context(self):
+        if self._ctx is None:
+            from . import hip_api
+            self._ctx = hip_api.Context(self._device)
+        return self._ctx
+
+    def forces_kwargs(self):
+        """Arguments of hip_api.Context.set_forces for this run (what state() reads off
+        ``output``: state.py:19,27,34-36,44-52)."""
+        opt = self.inputs.options
+        photo = None
+        if self.loss_info is not None and self.loss_info.photo is not None:
+            photo = float(self.loss_info.photo)
+        kw = dict(GM=float(self.GM), vrplanet=float(self.vrplanet),
+                  gravity=bool(self.inputs.forces.gravity),
+                  radpres=bool(self.inputs.forces.radpres),
+                  lifetime=float(opt.lifetime.value), photo=photo)
+        if self.radpres is not None:
+            kw.update(v_tab=self.radpres.velocity, a_tab=self.radpres.accel)
+        return kw
+
+    def x0_soa(self):
+        """Initial state as the (8, N) struct-of-arrays block the C ABI takes."""
+        return np.ascontiguousarray(self.X0[STATE_COLS].values.T, dtype=np.float64)
+
+    def _raise_on_counters(self, ctr):
+        self.counters = ctr
+        assert ctr.get('nonfinite', 0) == 0, '\n\tInfinite values of emax'
+        assert ctr.get('neg_frac', 0) == 0, 'Found new values of frac that are negative'
+        assert ctr.get('bad_step', 0) == 0, 'Bad step size'
+
+    # ---- drivers --------------------------------------------------------------------------
+    def constant_step_size_driver(self, keep_trajectory=True):
+        """Output.py:368-455 on the GPU.  With keep_trajectory the lock-step kernel returns every
+        record and ``X`` is assembled exactly like the reference's (N*nsteps rows, columns
+        Index,time,x,y,z,vx,vy,vz,frac,lossfrac).  lossfrac starts from 0 (the reference's
+        starts from uninitialised memory, Output.py:378)."""
+        opt = self.inputs.options
+        endtime, step = opt.endtime.value, float(opt.step_size)
+        self.nsteps, n_iter = n_output_steps(endtime, step)
+        ctx = self.context()
+        ctx.set_forces(**self.forces_kwargs())
+        ctx.upload_soa(self.x0_soa())
+        n = self.npackets
+        if keep_trajectory:
+            res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)
+            self._raise_on_counters(ctx.counters())
+            traj = res['traj']                               # (8, nsteps, N)
+            X = pd.DataFrame()
+            X['Index'] = np.repeat(np.arange(n, dtype=np.int64), self.nsteps)
+            for k, name in enumerate(STATE_COLS):
+                X[name] = np.ascontiguousarray(traj[k].T).reshape(n*self.nsteps)
+            frac = traj[7].T                                 # (N, nsteps)
+            # lossfrac[:, ct] = lossfrac[:, ct-1] + frac[:, ct-1] - frac[:, ct] while the
+            # packet was active at ct-1 (Output.py:420-421)
+            d = np.zeros_like(frac)
+            active_prev = frac[:, :-1] > 0
+            d[:, 1:] = np.where(active_prev, frac[:, :-1] - frac[:, 1:], 0.0)
+            X['lossfrac'] = np.cumsum(d, axis=1).reshape(n*self.nsteps)
+            self.X = X
+        else:
+            ctx.integrate_const(step, n_iter, opt.outeredge)
+            self._raise_on_counters(ctx.counters())
+            self.X = pd.DataFrame()
+        self.totalsource *= self.nsteps                      # Output.py:434
+        self._add_units()
+
+    def variable_step_size_driver(self):
+        """Output.py:221-366 on the GPU: final snapshot, one row per packet."""
+        opt = self.inputs.options
+        ctx = self.context()
+        ctx.set_forces(**self.forces_kwargs())
+        ctx.upload_soa(np.ascontiguousarray(self.X[STATE_COLS].values.T, dtype=np.float64))
+        final, hs = ctx.integrate_var(float(opt.resolution), opt.outeredge)
+        ctr = ctx.counters()
+        self._raise_on_counters(ctr)
+        assert ctr.get('unfinished', 0) == 0, 'variable-step integration did not finish'
+        for k, name in enumerate(STATE_COLS):
+            self.X[name] = final[:, k]
+        self.X['step_size'] = hs
+        self.X['Index'] = self.X.index
+        self._add_units()
+
+    def _add_units(self):
+        # Output.py:363-366,452-455: aplanet in au, vrplanet in km/s, GM in R^3/s^2
+        self.aplanet = Quantity(self.aplanet, 'au')
+        self.vrplanet = Quantity(float(self.vrplanet)*self.unit_km, 'km/s')
+        self.GM = Quantity(self.GM, 'R3/s2')
+
+    def vrplanet_Rs(self):
+        """vrplanet back in R/s, as ModelImage.create_image converts it (ModelImage.py:242-243)."""
+        v = self.vrplanet
+        return float(v)/self.unit_km if isinstance(v, Quantity) and v.unit == 'km/s' else float(v)
+
+    # ---- persistence (file catalogue instead of PostgreSQL + pickle) ------------------------
+    def save(self):
+        """Apply the reference's on-disk transformations (compress filter, 32-bit down-cast,
+        Output.py:522-543), register in the inputs' catalogue, optionally write an .npz."""
+        if self.compress and len(self.X) > 0 and 'frac' in self.X:
+            self.X = self.X[self.X.frac > 0]
+        for frame in (self.X0, self.X):
+            for column in frame:
+                if frame[column].dtype == np.int64:
+                    frame[column] = frame[column].astype(np.int32)
+                elif frame[column].dtype == np.float64:
+                    frame[column] = frame[column].astype(np.float32)
+        catalogue = getattr(self.inputs, '_catalogue', None)
+        if catalogue is not None:
+            self.idnum = len(catalogue) + 1
+            savepath = getattr(self.inputs, 'savepath', None)
+            if savepath:
+                os.makedirs(savepath, exist_ok=True)
+                self.filename = os.path.join(savepath, f'{self.idnum:010d}.npz')
+                self._write(self.filename)
+            catalogue.append(self)
+
+    def _write(self, filename):
+        data = {f'X0.{c}': self.X0[c].values for c in self.X0}
+        data.update({f'X.{c}': self.X[c].values for c in self.X})
+        np.savez(filename, npackets=self.npackets, totalsource=self.totalsource,
+                 nsteps=self.nsteps or 0, aplanet=float(self.aplanet),
+                 vrplanet_kms=float(self.vrplanet), compress=self.compress, **data)
+
+    @staticmethod
+    def upcast(frame):
+        """restore()'s 32 -> 64 bit conversion (Output.py:555-570)."""
+        for column in frame:
+            if frame[column].dtype == np.int32:
+                frame[column] = frame[column].astype(np.int64)
+            elif frame[column].dtype == np.float32:
+                frame[column] = frame[column].astype(np.float64)
+        return frame
+
+    @classmethod
+    def restore(cls, source):
+        """Return an Output with 64-bit columns from a catalogued Output or an .npz file."""
+        if isinstance(source, cls):
+            out = source
+            cls.upcast(out.X0)
+            cls.upcast(out.X)
+            return out
+        data = np.load(source, allow_pickle=False)
+        out = cls.__new__(cls)
+        out.filename = source
+        out.npackets = int(data['npackets'])
+        out.totalsource = float(data['totalsource'])
+        out.nsteps = int(data['nsteps'])
+        out.aplanet = Quantity(float(data['aplanet']), 'au')
+        out.vrplanet = Quantity(float(data['vrplanet_kms']), 'km/s')
+        out.compress = bool(data['compress'])
+        out.X0 = pd.DataFrame({k[3:]: data[k] for k in data.files if k.startswith('X0.')})
+        out.X = pd.DataFrame({k[2:]: data[k] for k in data.files if k.startswith('X.')})
+        cls.upcast(out.X0)
+        cls.upcast(out.X)
+        return out
