@@ -46,49 +46,8 @@ def parse():
     p.add_argument('--dims', type=int, default=512)
     p.add_argument('--quantity', default='radiance')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-packets', type=int, default=30_000)
+    p.add_argument('--cpu-packets', type=int, default=150_000)
     return p.parse_args()
-
-
-class ControlPlane:
-    """Barrier / scalar reductions / byte broadcast across ranks (gloo on CPU); trivial at N=1."""
-
-    def __init__(self, world):
-        self.world = world
-        self.rank = int(os.environ.get('RANK', '0'))
-        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self.dist = None
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29511')
-            dist.init_process_group(backend='gloo', rank=self.rank, world_size=world)
-            self.dist, self.torch = dist, torch
-
-    def barrier(self):
-        if self.dist:
-            self.dist.barrier()
-
-    def reduce(self, value, op):
-        if not self.dist:
-            return value
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
-        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
-        return float(t[0])
-
-    def bcast_bytes(self, payload, n):
-        if not self.dist:
-            return payload
-        t = self.torch.zeros(n, dtype=self.torch.uint8)
-        if self.rank == 0:
-            t = self.torch.tensor(list(payload), dtype=self.torch.uint8)
-        self.dist.broadcast(t, src=0)
-        return bytes(t.tolist())
-
-    def close(self):
-        if self.dist:
-            self.dist.destroy_process_group()
 
 
 def cpu_baseline(args, inputs):
@@ -129,13 +88,11 @@ def cpu_baseline(args, inputs):
 
 def main():
     args = parse()
-    world = int(os.environ.get('WORLD_SIZE', str(args.gpus)))
-    if 'RANK' not in os.environ:
-        world = 1
+    from nexoclom_amd import Input, Output, ModelImage, hip_api
+    from nexoclom_amd.distributed import ControlPlane
+    world = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
     cp = ControlPlane(world)
     rank = cp.rank
-
-    from nexoclom_amd import Input, Output, ModelImage, hip_api
     from nexoclom_amd.Output import n_output_steps
 
     infile = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
@@ -164,9 +121,7 @@ def main():
 
     reduce_mode = 'none'
     if world > 1:
-        uid = ctx.comm_unique_id() if rank == 0 else b''
-        uid = cp.bcast_bytes(uid, hip_api.NXC_UNIQUE_ID_BYTES)
-        ctx.comm_init(uid, rank, world)
+        cp.init_rccl(ctx)
         reduce_mode = 'rccl-allreduce'
 
     def one_step():

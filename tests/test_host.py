@@ -1,0 +1,165 @@
+"""Host-side logic: inputfile parser, physical tables, X0 sampling (no GPU)."""
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+import nexoclom_amd
+from nexoclom_amd import Input, Output, PhotoRate, RadPresConst, SSObject, gValue, planet_dist
+from nexoclom_amd.input_classes import InputError
+from nexoclom_amd.Output import n_output_steps
+from nexoclom_amd.source_distribution import xyz_from_lonlat
+from tests import helpers as H
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_INPUTS = os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles')
+
+
+def test_photorate_known_answers():
+    """tests/unit_tests/atomicdata/test_photolossrates.py:7-9 of the reference."""
+    assert PhotoRate('Na', 1.5).rate.value == 3.2266666666666665e-06
+    assert PhotoRate('Ca', 0.3).rate.value == 7.777777777777777e-4
+    assert PhotoRate('X', 1.).rate.value == 1e-30
+
+
+def test_mercury_setup_numbers():
+    """Numbers obtained from the reference itself during the survey."""
+    m = SSObject('mercury')
+    assert m.object == 'Mercury' and m.type == 'Planet' and m.moons is None
+    r, v = planet_dist(m, 1.3)
+    assert float(r) == 0.35140097909804036
+    assert abs(float(v)/9.730746760831499 - 1) < 1e-12
+    R = m.radius.value*1e3
+    assert abs(m.GM.value/R**3/(-1.51566332945409e-06) - 1) < 1e-14
+    assert PhotoRate('Na', float(r)).rate.value == 5.8793685680196064e-05
+    rp = RadPresConst('Na', float(r))
+    assert len(rp.velocity) == 827 and np.all(np.diff(rp.velocity) > 0)
+    assert abs(rp.accel.max()*1e5 - 361.09) < 0.01            # cm/s^2
+    assert rp.velocity.min() == -50.6857 and rp.velocity.max() == 49.5196
+    assert len(RadPresConst('Ca', 0.3).velocity) == 319
+    assert len(RadPresConst('Mg', 0.3).velocity) == 179
+    g = gValue('Na', 5891, 1.5)
+    assert len(g.velocity) == 389 and np.all(np.diff(g.velocity) > 0)
+    assert gValue('Zz', 1234).g.tolist() == [0., 0.]
+    jup = SSObject('Jupiter')
+    assert len(jup) == 5 and {x.object for x in jup.moons} == {'Io', 'Europa', 'Ganymede', 'Callisto'}
+
+
+def test_xyz_from_lonlat_known_points():
+    """tests/unit_tests/Initial_state/test_xyz_from_latlon.py of the reference: planet and
+    satellite longitude conventions."""
+    lon = np.array([0, np.pi/2, np.pi, 3*np.pi/2])
+    p = xyz_from_lonlat(lon, np.zeros(4), True, 1.0)
+    assert np.allclose(p.T, [[0, -1, 0], [1, 0, 0], [0, 1, 0], [-1, 0, 0]], atol=1e-15)
+    s = xyz_from_lonlat(lon, np.zeros(4), False, 1.0)
+    assert np.allclose(s.T, [[0, -1, 0], [-1, 0, 0], [0, 1, 0], [1, 0, 0]], atol=1e-15)
+    lat = np.array([-np.pi/2, 0, np.pi/2])
+    mer = xyz_from_lonlat(np.zeros(3), lat, True, 2.0)
+    assert np.allclose(mer.T, [[0, 0, -2], [0, -2, 0], [0, 0, 2]], atol=1e-15)
+
+
+def test_parser_defaults_and_rules():
+    inp = Input(os.path.join(HERE, 'inputfiles', 'Gravity.input'))
+    assert inp.geometry.planet.object == 'Mercury' and inp.geometry.taa == 3.14
+    assert inp.geometry.type == 'geometry without starttime' and inp.geometry.phi is None
+    assert inp.forces.gravity is True and inp.forces.radpres is False
+    assert inp.surfaceinteraction.sticktype == 'constant'
+    assert inp.surfaceinteraction.stickcoef == 1. and inp.surfaceinteraction.accomfactor is None
+    assert inp.spatialdist.type == 'uniform' and inp.spatialdist.exobase == 1.
+    assert [float(x) for x in inp.spatialdist.longitude] == [0., 2*np.pi]
+    assert inp.speeddist.type == 'flat' and inp.speeddist.vprob.value == 4.
+    assert inp.angulardist.type == 'isotropic'
+    assert [float(x) for x in inp.angulardist.altitude] == [0., np.pi/2]
+    assert inp.options.endtime.value == 20000. and inp.options.step_size == 30.
+    assert inp.options.outeredge == 1e30 and inp.options.resolution is None
+    assert inp.options.species == 'Na' and inp.options.lifetime.value == 0.
+
+    reg = Input(os.path.join(HERE, 'inputfiles', 'Spatial.region.input'))
+    assert reg.spatialdist.exobase == 2.1
+    assert [float(x) for x in reg.spatialdist.latitude] == [0., 0.79]
+    assert reg.speeddist.type == 'gaussian' and reg.speeddist.sigma.value == 0.5
+    assert reg.angulardist.type == 'radial'
+    assert reg.options.species == 'Na'            # capitalised (input_classes.py:1069)
+    assert reg.options.outeredge == 12 and reg.options.step_size == 0.
+    assert reg.options.resolution == 1e-4 and reg.options.lifetime.value == -7200.
+    assert reg == Input(os.path.join(HERE, 'inputfiles', 'Spatial.region.input'))
+    assert reg != inp
+    with pytest.raises(FileNotFoundError):
+        Input('/nonexistent.input')
+
+
+def test_parser_errors(tmp_path):
+    p = tmp_path / 'bad.input'
+    p.write_text('SpatialDist.type = uniform\nSpeedDist.type = flat\noptions.endtime = 10\n'
+                 'options.species = Na\n')
+    with pytest.raises(InputError):
+        Input(str(p))                              # no geometry.planet
+    p.write_text('geometry.planet = Mercury\nSpatialDist.type = uniform\nSpeedDist.type = flat\n'
+                 'SpeedDist.vprob = 1\noptions.endtime = 10\noptions.species = Na\n')
+    with pytest.raises(InputError):
+        Input(str(p))                              # flat without delv
+    p.write_text('geometry.planet = Mercury\nSpatialDist.type = uniform\n'
+                 'SpatialDist.latitude = 1, 0\nSpeedDist.type = flat\nSpeedDist.vprob = 1\n'
+                 'SpeedDist.delv = 1\noptions.endtime = 10\noptions.species = Na\n')
+    with pytest.raises(InputError):
+        Input(str(p))                              # latitude[0] > latitude[1]
+
+
+def test_n_output_steps_matches_reference_rule():
+    assert n_output_steps(50000., 30.) == (1668, 1667)
+    assert n_output_steps(10800., 30.) == (361, 360)
+    assert n_output_steps(20000., 30.) == (668, 667)
+    assert n_output_steps(100., 30.) == (5, 4)
+
+
+def test_chunk_rule():
+    inp = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    assert inp.chunk_size() == 80467              # ceil(1024^3/1668/8), SURVEY.md section 3.1
+    inp.options.step_size = 0
+    assert inp.chunk_size() == 1000000
+
+
+def test_x0_sampling_is_seed_deterministic_and_ordered():
+    inp = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    a = Output(inp, 5000, seed=1234, integrate=False, save=False)
+    b = Output(inp, 5000, seed=1234, integrate=False, save=False)
+    assert a.X0.equals(b.X0)
+    cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']
+    assert list(a.X0.columns) == cols + ['v', 'longitude', 'latitude', 'local_time', 'altitude',
+                                         'azimuth']
+    # independent restatement of the draw order (tests/helpers.sample_x0)
+    assert np.array_equal(a.X0[cols].values, H.sample_x0(5000, 1234, 50000.))
+    X = a.X0
+    assert np.allclose(np.sqrt(X.x**2 + X.y**2 + X.z**2), 1.0)
+    speed = np.sqrt(X.vx**2 + X.vy**2 + X.vz**2)*a.unit_km
+    assert speed.min() >= 0.5 and speed.max() <= 4.5
+    # outward launch: v . r > 0
+    assert np.all(X.vx*X.x + X.vy*X.y + X.vz*X.z > 0)
+    kw = a.forces_kwargs()
+    assert kw['GM'] < 0 and kw['photo'] == 5.8793685680196064e-05 and len(kw['v_tab']) == 827
+
+
+def test_uniform_surface_sampling_statistics():
+    """KS tests in the spirit of the reference's test_spatial_distribution.py:95-143."""
+    inp = Input(os.path.join(HERE, 'inputfiles', 'Spatial.region.input'))
+    inp.options.step_size = 30.
+    out = Output(inp, 100000, seed=7, integrate=False, save=False)
+    lon, lat = out.X0.longitude.values, out.X0.latitude.values
+    assert lon.min() >= 0 and lon.max() <= 3.14 and lat.min() >= 0 and lat.max() <= 0.79
+    assert stats.kstest(lon, 'uniform', args=(0, 3.14)).pvalue > 1e-3
+    assert stats.kstest(np.sin(lat), 'uniform', args=(0, np.sin(0.79))).pvalue > 1e-3
+    r = np.sqrt(out.X0.x**2 + out.X0.y**2 + out.X0.z**2)
+    assert np.allclose(r, 2.1)
+    # radial launch: velocity parallel to position
+    v = out.X0[['vx', 'vy', 'vz']].values
+    p = out.X0[['x', 'y', 'z']].values
+    assert np.allclose(np.cross(v, p), 0, atol=1e-12)
+    assert out.loss_info.photo == 1/7200.
+
+
+def test_bounce_and_moons_are_refused():
+    inp = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    inp.surfaceinteraction.stickcoef = 0.5
+    with pytest.raises(NotImplementedError):
+        Output(inp, 10, seed=1, integrate=False, save=False)

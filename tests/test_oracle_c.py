@@ -1,0 +1,69 @@
+"""Pins of the C oracle's own building blocks (oracle/c/oracle_math.h) and of the exactness
+arguments the HIP kernels rely on."""
+from fractions import Fraction
+
+import numpy as np
+
+from oracle.c_oracle import COracle
+
+
+def ulps(a, b):
+    return np.abs(a - b)/np.spacing(np.maximum(np.abs(a), np.abs(b)))
+
+
+def test_cube_is_correctly_rounded(coracle):
+    rng = np.random.default_rng(0)
+    r = np.concatenate([rng.uniform(0.5, 40, 20000), 10**rng.uniform(-3, 3, 2000)])
+    exact = np.array([float(Fraction(v)**3) for v in r])
+    assert np.array_equal(coracle.math('cube', r), exact)
+
+
+def test_exp_log_within_one_ulp_of_libm(coracle):
+    libm = COracle(libm=True)
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-rng.uniform(0, 40, 200000), rng.uniform(-1e-9, 1e-9, 100),
+                        [0.0, -0.34, -0.35, -1.03, -1.04, -700.0]])
+    assert ulps(coracle.math('exp', x), libm.math('exp', x)).max() <= 1.0
+    f = np.concatenate([rng.uniform(1e-10, 1, 200000), 10**rng.uniform(-300, 300, 2000),
+                        [1.0, 0.5, 2.0, 1e-10, np.nextafter(1.0, 0), np.nextafter(1.0, 2)]])
+    assert ulps(coracle.math('log', f), libm.math('log', f)).max() <= 1.0
+    assert coracle.math('log', np.array([1.0]))[0] == 0.0
+    assert coracle.math('exp', np.array([0.0]))[0] == 1.0
+
+
+def test_sqrt_threshold_equivalences():
+    """sqrt(s) > 1 <=> s > 1+2^-52 and sqrt(s) < 1 <=> s < 1 for correctly rounded sqrt: the
+    kernels test s directly instead of taking the root (nxc_device.hpp sunlit / apply_fate)."""
+    one = 1.0
+    s = np.array([np.nextafter(one, 0), one, np.nextafter(one, 2),
+                  np.nextafter(np.nextafter(one, 2), 2), 1 - 1e-15, 1 + 1e-15, 0.25, 4.0])
+    root = np.sqrt(s)
+    assert np.array_equal(root > 1, s > float.fromhex('0x1.0000000000001p+0'))
+    assert np.array_equal((root - 1.0) < 0, s < 1.0)
+    rng = np.random.default_rng(2)
+    t = 1 + rng.integers(-64, 64, 4096)*2.0**-53
+    assert np.array_equal(np.sqrt(t) > 1, t > float.fromhex('0x1.0000000000001p+0'))
+    assert np.array_equal(np.sqrt(t) < 1, t < 1.0)
+
+
+def test_libm_variant_agrees_to_tolerance(coracle):
+    from tests import helpers as H
+    libm = COracle(libm=True)
+    f = H.mercury_forces('Na', 1.3)
+    X = H.random_cloud(2048, 3)
+    h = np.zeros(len(X)) + 30.
+    a, _ = coracle.rk5(f, X, h)
+    b, _ = libm.rk5(f, X, h)
+    np.testing.assert_allclose(a, b, rtol=1e-14, atol=1e-20)
+
+
+def test_threads_do_not_change_states(coracle):
+    from oracle import np_oracle as O
+    from tests import helpers as H
+    f = H.mercury_forces('Na', 1.3)
+    X0 = H.sample_x0(1500, 77, 50000.)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    a = coracle.integrate_const(f, X0, 30., n_iter, 25., threads=1)
+    b = coracle.integrate_const(f, X0, 30., n_iter, 25., threads=4)
+    assert a['work'] == b['work'] and np.array_equal(a['final'], b['final'])
+    assert np.array_equal(a['steps'], b['steps'])

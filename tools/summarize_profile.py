@@ -1,0 +1,51 @@
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 CSVs from tools/profile.sh) into profiles/<tag>_*.
+
+Writes profiles/<tag>_kernel_stats.csv (the --stats summary), profiles/<tag>_pmc.json (per-launch
+counter averages per kernel) and updates profiles/traffic.json (HBM bytes per launch of the
+dominant kernel, FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": gfx950 reports half the bytes
+of a wide coalesced read; WRITE_SIZE taken as is; both are in KiB units -> x1024)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+for f in glob.glob(os.path.join(src, 'trace', '**', '*_kernel_stats.csv'), recursive=True):
+    shutil.copy(f, os.path.join(dst, f'{tag}_kernel_stats.csv'))
+bl = os.path.join(src, 'bench_line.json')
+if os.path.exists(bl):
+    shutil.copy(bl, os.path.join(dst, f'{tag}_bench_line.json'))
+
+pmc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, '*', '**', '*_counter_collection.csv'), recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row['Kernel_Name'].split('(')[0]
+        pmc[name][row['Counter_Name']].append(float(row['Counter_Value']))
+summary = {k: {c: {'mean_per_launch': sum(v)/len(v), 'launches': len(v)} for c, v in d.items()}
+           for k, d in pmc.items()}
+json.dump(summary, open(os.path.join(dst, f'{tag}_pmc.json'), 'w'), indent=1, sort_keys=True)
+
+dom = [k for k in summary if 'k_const_fused' in k]
+traffic = {}
+if dom:
+    s = summary[dom[0]]
+    if 'FETCH_SIZE' in s and 'WRITE_SIZE' in s:
+        fetch = s['FETCH_SIZE']['mean_per_launch']*1024*2
+        write = s['WRITE_SIZE']['mean_per_launch']*1024
+        traffic = {'k_const_fused_bytes_per_launch': fetch + write, 'fetch_bytes_corrected': fetch,
+                   'write_bytes': write, 'tag': tag,
+                   'note': 'FETCH_SIZE x2 (gfx950 half-count of wide reads), KiB units x1024'}
+        json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+print(json.dumps({'kernels': list(summary), 'traffic': traffic}, indent=1))
+for k, d in summary.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print(f'   {c:28s} {v["mean_per_launch"]:.6g}')
