@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,7 +38,7 @@ int fail(int code, const std::string &msg)
             return fail(NXC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
-constexpr int BLOCK_PERSIST = NXC_BLOCK;
+constexpr int BLOCK_PERSIST = NXC_BLOCK_PERSIST;
 
 // ---- RCCL, resolved at first use ------------------------------------------------------------
 struct Rccl {
@@ -94,31 +96,51 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
         if (!(xp[j + 1] > xp[j]))
             return fail(NXC_ERR_ARG, std::string(what) + ": abscissae must be strictly ascending");
     int ncell = 64;
-    while (ncell < 2 * n && ncell < 8192) ncell <<= 1;
-    const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 7) & ~size_t(7);
-    out.bytes.assign((size_t)3 * n * sizeof(double) + cell_bytes, 0);
-    double *base = reinterpret_cast<double *>(out.bytes.data());
-    std::memcpy(base, xp, n * sizeof(double));
-    std::memcpy(base + n, fp, n * sizeof(double));
-    for (int64_t j = 0; j + 1 < n; j++)      // np.interp's slope, same IEEE quotient
-        base[2 * n + j] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-    unsigned short *cell = reinterpret_cast<unsigned short *>(base + 3 * n);
+    while (ncell < 4 * n && ncell < 16384) ncell <<= 1;
+    const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 31) & ~size_t(31);
+    out.bytes.assign((size_t)n * 32 + cell_bytes, 0);
+    double *rec = reinterpret_cast<double *>(out.bytes.data());
+    for (int64_t j = 0; j < n; j++) {
+        rec[4 * j + 0] = xp[j];
+        rec[4 * j + 1] = fp[j];
+        if (j + 1 < n) {      // np.interp's slope, the same IEEE quotient
+            rec[4 * j + 2] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+            rec[4 * j + 3] = xp[j + 1];
+        } else {
+            rec[4 * j + 2] = 0.0;
+            rec[4 * j + 3] = HUGE_VAL;
+        }
+        if (!std::isfinite(rec[4 * j + 1]) || !std::isfinite(rec[4 * j + 2]))
+            return fail(NXC_ERR_ARG, std::string(what) + ": table values must be finite");
+    }
+    unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * n);
     const double x0 = xp[0], xl = xp[n - 1];
     const double inv_w = (double)ncell / (xl - x0);
     for (int c = 0; c <= ncell; c++) {
         const double edge = x0 + (double)c / inv_w;
-        int64_t j = std::upper_bound(xp, xp + n, edge) - xp - 1;   // xp[j] <= edge
-        j = std::max<int64_t>(0, j - 1);                           // margin for rounding
-        cell[c] = (unsigned short)j;
+        int64_t j = std::upper_bound(xp, xp + n, edge) - xp - 1;   // largest j with xp[j] <= edge
+        cell[c] = (unsigned short)std::max<int64_t>(0, std::min<int64_t>(j, n - 1));
     }
     out.desc.n = (int)n;
     out.desc.ncell = ncell;
     out.desc.x0 = x0;
     out.desc.xlast = xl;
+    out.desc.f_first = fp[0];
+    out.desc.f_last = fp[n - 1];
     out.desc.inv_w = inv_w;
     out.desc.offset_bytes = 0;
     out.desc.size_bytes = (int64_t)out.bytes.size();
     return NXC_OK;
+}
+
+// h*a[n+1][i] for a launch-uniform step: the products NumPy forms per packet (rk5.py:33).
+StepW make_stepw(double h)
+{
+    StepW w{};
+    w.h = h;
+    for (int n = 0; n < 6; n++)
+        for (int i = 0; i <= n; i++) w.w[n * (n + 1) / 2 + i] = h * Tableau::A[n + 1][i];
+    return w;
 }
 
 }  // namespace
@@ -137,6 +159,7 @@ struct nxc_handle {
     ImageK G{};
     PackedLut force_lut;
     std::vector<unsigned char> image_part;       // lines, then xedges, zedges
+    LdsHeader header{};                          // host copy of the blob's first bytes
     LutDesc line_local[NXC_MAX_LINES]{};
     int64_t xedges_local = 0, zedges_local = 0;
     unsigned char *d_blob = nullptr;
@@ -173,31 +196,46 @@ int ensure(void **ptr, size_t *cap, size_t bytes)
     return NXC_OK;
 }
 
+// Device blob = [LdsHeader | force table | g-value tables | x edges | z edges]; kernels stage
+// the first force_bytes (integrator only) or all_bytes (image) of it into LDS.
 int upload_blob(nxc_handle *h)
 {
+    const size_t hb = NXC_HEADER_BYTES;
     const size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
     const size_t ib = h->have_image ? h->image_part.size() : 0;
-    h->force_bytes = fb;
-    h->all_bytes = fb + ib;
-    if (h->all_bytes > 160 * 1024)
+    h->force_bytes = hb + fb;
+    h->all_bytes = hb + fb + ib;
+    if (h->all_bytes + 32 + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES > 160 * 1024)
         return fail(NXC_ERR_ARG, "lookup tables exceed the 160 KiB LDS of a gfx950 CU");
     int rc = ensure(reinterpret_cast<void **>(&h->d_blob), &h->blob_cap, h->all_bytes);
     if (rc) return rc;
-    if (fb) HIPCHK(hipMemcpyAsync(h->d_blob, h->force_lut.bytes.data(), fb, hipMemcpyHostToDevice,
-                                  h->stream));
-    if (ib) HIPCHK(hipMemcpyAsync(h->d_blob + fb, h->image_part.data(), ib, hipMemcpyHostToDevice,
-                                  h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     h->F.tab = h->force_lut.desc;
-    h->F.tab.offset_bytes = 0;
+    h->F.tab.offset_bytes = (int64_t)hb;
     if (h->have_image) {
         for (int l = 0; l < h->G.n_lines; l++) {
             h->G.line[l] = h->line_local[l];
-            h->G.line[l].offset_bytes += (int64_t)fb;
+            h->G.line[l].offset_bytes += (int64_t)(hb + fb);
         }
-        h->G.xedges_off = h->xedges_local + (int64_t)fb;
-        h->G.zedges_off = h->zedges_local + (int64_t)fb;
+        h->G.xedges_off = h->xedges_local + (int64_t)(hb + fb);
+        h->G.zedges_off = h->zedges_local + (int64_t)(hb + fb);
     }
+    h->header.G = h->G;
+    HIPCHK(hipMemcpyAsync(h->d_blob, &h->header, sizeof(LdsHeader), hipMemcpyHostToDevice,
+                          h->stream));
+    if (fb) HIPCHK(hipMemcpyAsync(h->d_blob + hb, h->force_lut.bytes.data(), fb,
+                                  hipMemcpyHostToDevice, h->stream));
+    if (ib) HIPCHK(hipMemcpyAsync(h->d_blob + hb + fb, h->image_part.data(), ib,
+                                  hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+// Put this launch's step weights into the header (stream-ordered before the kernel).
+int upload_step(nxc_handle *h, double step)
+{
+    h->header.W = make_stepw(step);
+    HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, W), &h->header.W, sizeof(StepW),
+                          hipMemcpyHostToDevice, h->stream));
     return NXC_OK;
 }
 
@@ -253,19 +291,26 @@ int need_forces(nxc_handle *h)
     return NXC_OK;
 }
 
+size_t persist_lds(size_t table_bytes)
+{
+    return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
+}
+
 int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, bool image,
                  double *d_final, long long *d_steps)
 {
-    const size_t lds = image ? h->all_bytes : h->force_bytes;
-    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    const size_t tables = image ? h->all_bytes : h->force_bytes;
+    const size_t lds = persist_lds(tables);
     int grid = 1, rc;
+    if ((rc = upload_step(h, step))) return rc;
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     if (image) {
         if ((rc = prep_kernel(k_const_fused<true>, lds))) return rc;
         if ((rc = persistent_grid(h, k_const_fused<true>, BLOCK_PERSIST, lds, h->n_packets, &grid)))
             return rc;
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<true>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
-                           h->F, h->G, h->d_blob, (int64_t)lds, h->n_packets, h->d_packets, step,
+                           h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
                            n_iter, outeredge, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
     } else {
         if ((rc = prep_kernel(k_const_fused<false>, lds))) return rc;
@@ -274,7 +319,7 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
             return rc;
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<false>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
-                           h->F, h->G, h->d_blob, (int64_t)lds, h->n_packets, h->d_packets, step,
+                           h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
                            n_iter, outeredge, d_final, d_steps, (double *)nullptr,
                            (unsigned long long *)nullptr, h->d_ctr);
     }
@@ -415,6 +460,7 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     G.quantity = d->quantity;
     G.n_lines = nl;
     G.downcast_f32 = d->downcast_f32 ? 1 : 0;
+    if (const char *dbg = std::getenv("NXC_DEBUG_IMAGE")) G.dbg = std::atoi(dbg);
     G.nx = (int)d->nx;
     G.nz = (int)d->nz;
     for (int l = 0; l < nl; l++) {
@@ -627,6 +673,7 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
                                      "packets per call (the reference chunks too, Input.py:219-222)");
         double *d_traj = nullptr;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes));
+        if ((rc = upload_step(h, step))) { (void)hipFree(d_traj); return rc; }
         hipError_t e = hipMemsetAsync(d_traj, 0, tbytes, h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
         const size_t lds = image ? h->all_bytes : h->force_bytes;
@@ -637,17 +684,17 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
                 rc = prep_kernel(k_const_traj<true>, lds);
                 if (!rc)
                     hipLaunchKernelGGL(k_const_traj<true>, dim3(grid), dim3(NXC_BLOCK), lds,
-                                       h->stream, h->F, h->G, h->d_blob, (int64_t)lds, n,
-                                       h->d_packets, step, n_iter, outeredge, d_traj, nrec, d_final,
-                                       d_steps, h->d_image, h->d_counts, h->d_ctr);
+                                       h->stream, h->F, h->d_blob,
+                                       (int64_t)lds, n, h->d_packets, n_iter, outeredge, d_traj,
+                                       nrec, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
             } else {
                 rc = prep_kernel(k_const_traj<false>, lds);
                 if (!rc)
                     hipLaunchKernelGGL(k_const_traj<false>, dim3(grid), dim3(NXC_BLOCK), lds,
-                                       h->stream, h->F, h->G, h->d_blob, (int64_t)lds, n,
-                                       h->d_packets, step, n_iter, outeredge, d_traj, nrec, d_final,
-                                       d_steps, (double *)nullptr, (unsigned long long *)nullptr,
-                                       h->d_ctr);
+                                       h->stream, h->F, h->d_blob,
+                                       (int64_t)lds, n, h->d_packets, n_iter, outeredge, d_traj,
+                                       nrec, d_final, d_steps, (double *)nullptr,
+                                       (unsigned long long *)nullptr, h->d_ctr);
             }
             if (!rc) e = hipGetLastError();
         }
@@ -685,12 +732,12 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     double *d_final = h->d_scratch, *d_hs = d_final + 8 * n;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     int grid = 1;
-    const size_t lds = h->force_bytes;
+    const size_t lds = persist_lds(h->force_bytes);
     if ((rc = prep_kernel(k_var, lds))) return rc;
     if ((rc = persistent_grid(h, k_var, BLOCK_PERSIST, lds, n, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_var, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)lds, n, h->d_packets, resolution, outeredge, (long long)max_steps,
+                       (int64_t)h->force_bytes, n, h->d_packets, resolution, outeredge, (long long)max_steps,
                        d_final, d_hs, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
@@ -719,7 +766,7 @@ int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double
     if ((rc = prep_kernel(k_image, h->all_bytes))) return rc;
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_image, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
-                       h->stream, h->G, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
+                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
                        d + 3 * p, d + 4 * p, h->d_image, h->d_counts, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;

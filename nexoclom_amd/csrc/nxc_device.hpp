@@ -13,30 +13,32 @@
 
 // ---------------------------------------------------------------------------------------------
 // Lookup table with np.interp semantics (numpy compiled_base.c arr_interp): clamp to the end
-// values outside the table, fp[j] when x hits a node, else slope_j*(x - xp[j]) + fp[j] with
-// slope_j = (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) (computed once on the host: same IEEE quotient).
+// values outside the table, else slope_j*(x - xp[j]) + fp[j] with
+// slope_j = (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) (computed once on the host: same IEEE quotient; at a
+// node the product is +-0 and the sum is fp[j], np.interp's special case).
 //
-// Global image of one table (doubles unless noted), staged verbatim into LDS:
-//   [0 .. n)        xp
-//   [n .. 2n)       fp
-//   [2n .. 3n)      slope (last entry unused)
-//   then (ncell+1) uint16 cell->index entries, padded to a multiple of 8 bytes.
-// cell[c] is an index j with xp[j] <= left edge of uniform cell c (a lower bound good to a few
-// entries); the search walks from there, so the result is exactly the j of a bisection whatever
-// the rounding of the cell computation.
+// Global image of one table, staged verbatim into LDS (32-byte aligned):
+//   n records {xp[j], fp[j], slope[j], xp[j+1]}  (last: slope 0, xp[n] = +inf)
+//   then (ncell+1) uint16 cell->index entries, padded to a multiple of 32 bytes.
+// cell[c] = the largest j with xp[j] <= left edge of uniform cell c.  A lookup is two dependent
+// LDS round trips: the cell entry, then records j and j+1 (four ds_read_b128); the record whose
+// [xp, xp_next) holds x is selected.  Cells are fine enough (ncell >= 4n) that this almost always
+// hits; otherwise a walk over the records finds the interval, so the result is exactly the j of
+// np.interp's bisection whatever the rounding of the cell computation.
 // ---------------------------------------------------------------------------------------------
 struct LutDesc {          // host-filled, passed by value in kernel arguments
     int n;                // table length
     int ncell;            // number of uniform cells over [x0, xlast]
     double x0, xlast;     // xp[0], xp[n-1]
+    double f_first, f_last;   // fp[0], fp[n-1] (np.interp's left/right values)
     double inv_w;         // ncell / (xlast - x0)
-    int64_t offset_bytes; // byte offset of this table inside the packed table blob
-    int64_t size_bytes;   // bytes of this table in the blob (multiple of 8)
+    int64_t offset_bytes; // byte offset of this table inside the packed table blob (32-aligned)
+    int64_t size_bytes;   // bytes of this table in the blob (multiple of 32)
 };
 
 // All tables live in the workgroup's dynamic LDS block; they are addressed by byte offset from
 // its base so that every access is visibly an LDS (ds_read) access to the compiler.
-extern __shared__ __align__(16) unsigned char nxc_lds[];
+extern __shared__ __align__(32) unsigned char nxc_lds[];
 
 NXC_DEV double lds_f64(int byte_off)
 {
@@ -47,37 +49,51 @@ NXC_DEV int lds_u16(int byte_off)
     return *reinterpret_cast<const unsigned short *>(nxc_lds + byte_off);
 }
 
+struct LutRec { double xp, fp, sl, xn; };
+
+NXC_DEV LutRec lds_rec(int byte_off)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(nxc_lds + byte_off);
+    const double2 a = p[0], b = p[1];
+    return LutRec{a.x, a.y, b.x, b.y};
+}
+
 struct LutView {          // byte offsets into the LDS block
-    int xp, fp, sl, cell;
+    int rec, cell;
     int n, ncell;
-    double x0, xlast, inv_w;
+    double x0, xlast, f_first, f_last, inv_w;
 };
 
 NXC_DEV LutView lut_view(const LutDesc &d)
 {
     LutView v;
-    v.xp = (int)d.offset_bytes;
-    v.fp = v.xp + 8 * d.n;
-    v.sl = v.xp + 16 * d.n;
-    v.cell = v.xp + 24 * d.n;
-    v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast; v.inv_w = d.inv_w;
+    v.rec = (int)d.offset_bytes;
+    v.cell = v.rec + 32 * d.n;
+    v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast;
+    v.f_first = d.f_first; v.f_last = d.f_last; v.inv_w = d.inv_w;
     return v;
 }
 
 NXC_DEV double lut_interp(const LutView &t, double x)
 {
     if (x != x) return x;
-    if (x > t.xlast) return lds_f64(t.fp + 8 * (t.n - 1));
-    if (x < t.x0) return lds_f64(t.fp);
+    if (x > t.xlast) return t.f_last;
+    if (x < t.x0) return t.f_first;
     int c = (int)((x - t.x0) * t.inv_w);
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
-    while (j > 0 && lds_f64(t.xp + 8 * j) > x) --j;
-    while (j + 1 < t.n && lds_f64(t.xp + 8 * (j + 1)) <= x) ++j;
-    const double xj = lds_f64(t.xp + 8 * j);
-    const double fj = lds_f64(t.fp + 8 * j);
-    if (j == t.n - 1 || xj == x) return fj;
-    return lds_f64(t.sl + 8 * j) * (x - xj) + fj;
+    const int j1 = j + 1 < t.n ? j + 1 : t.n - 1;
+    LutRec r = lds_rec(t.rec + 32 * j);
+    const LutRec r1 = lds_rec(t.rec + 32 * j1);
+    const bool in0 = (x >= r.xp) && (x < r.xn);
+    const bool in1 = (x >= r1.xp) && (x < r1.xn);
+    if (!in0) r = r1;
+    if (!(in0 || in1)) {                       // rare: walk to the interval
+        while (j > 0 && x < lds_f64(t.rec + 32 * j)) --j;
+        while (x >= lds_f64(t.rec + 32 * j + 24)) ++j;
+        r = lds_rec(t.rec + 32 * j);
+    }
+    return r.sl * (x - r.xp) + r.fp;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,13 +157,22 @@ struct Tableau {
                                      -92097. / 339200., 187. / 2100., 1. / 40.};
 };
 
+// Precomputed h*a[n+1][i] for a launch-uniform step (the same IEEE products NumPy forms per packet,
+// rk5.py:33); index n(n+1)/2 + i.  Kept in scalar registers.
+struct StepW {
+    double h;
+    double w[21];
+};
+
 // s[8] = t_remaining, x, y, z, vx, vy, vz, frac (in/out).  d[8] (DELTA only) = the reference's
 // error estimate |h * sum_{i<6} (B5-B4)_i k_i| (rk5.py:38-46; the 7th stage is left out there).
 // Each stage is accumulated from zero in the order i = 0..n with terms (h*a)*k and the initial
 // state added last (rk5.py:32-36); frac is carried as log(frac) (rk5.py:25,35,50).
-template <bool DELTA>
-NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double h, double (&d)[8])
+template <bool DELTA, bool UNIFORM_H>
+NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double h,
+                      const StepW &W, double (&d)[8])
 {
+    if (UNIFORM_H) h = W.h;
     double kv[6][3], ka[6][3], kl[6];
     const double x0 = s[1], y0 = s[2], z0 = s[3], vx0 = s[4], vy0 = s[5], vz0 = s[6];
     const double lf0 = nxc_log(s[7]);
@@ -159,7 +184,7 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
         double nx = 0.0, ny = 0.0, nz = 0.0, nvx = 0.0, nvy = 0.0, nvz = 0.0, nlf = 0.0;
 #pragma unroll
         for (int i = 0; i <= n; i++) {
-            const double w = h * Tableau::A[n + 1][i];
+            const double w = UNIFORM_H ? W.w[n * (n + 1) / 2 + i] : h * Tableau::A[n + 1][i];
             nx += w * kv[i][0];
             ny += w * kv[i][1];
             nz += w * kv[i][2];
@@ -214,12 +239,27 @@ NXC_DEV void apply_fate(double (&s)[8], double outeredge)
 struct ImageK {            // kernel-argument scalars of nxc_image_desc
     double M[9];
     double vrplanet, apix_cm2;
-    int quantity, n_lines, downcast_f32, pad_;
+    int quantity, n_lines, downcast_f32, dbg;   // dbg: timing experiments only (0 = normal)
     int nx, nz;
     double x_lo, x_inv_step, z_lo, z_inv_step;   // only to seed the edge search
     int64_t xedges_off, zedges_off;              // byte offsets of the edge arrays in the blob
     LutDesc line[4];
 };
+
+// Launch-uniform constants that are read once per sample / once per step live at offset 0 of the
+// LDS block instead of in scalar registers: together with the force constants they would exceed
+// the 102 SGPRs of a wave, and every spilled SGPR costs v_readlane/v_writelane VALU slots in a
+// VALU-bound kernel.  (StepW is defined above; ImageK here.)
+struct LdsHeader {
+    ImageK G;
+    StepW W;
+};
+constexpr int NXC_HEADER_BYTES = (int)((sizeof(LdsHeader) + 31) & ~size_t(31));
+
+NXC_DEV const LdsHeader &lds_header()
+{
+    return *reinterpret_cast<const LdsHeader *>(nxc_lds);
+}
 
 // np.histogram2d bin along one axis: searchsorted(edges, v, 'right') - 1, the right-most edge
 // folded into the last bin, everything else (NaN included) outside = -1.  The arithmetic guess
@@ -269,7 +309,8 @@ NXC_DEV int image_sample(const ImageK &G, double x, double y, double z,
     const int iz = bin_index(zo, (int)G.zedges_off, G.nz, G.z_lo, G.z_inv_step);
     if (ix < 0 || iz < 0) return 0;
     const int64_t pix = (int64_t)ix * G.nz + iz;
-    if (w != 0.0) unsafeAtomicAdd(&image[pix], w);
-    atomicAdd(&counts[pix], 1ull);
+    if (G.dbg == 1) return 1;
+    if (w != 0.0 && G.dbg != 3) unsafeAtomicAdd(&image[pix], w);
+    if (G.dbg != 2) atomicAdd(&counts[pix], 1ull);
     return 1;
 }

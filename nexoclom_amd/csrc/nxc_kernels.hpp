@@ -23,8 +23,13 @@ struct DevCounters {
         unfinished, queue_head;
 };
 
-constexpr int NXC_BLOCK = 256;      // threads per workgroup (4 waves)
-constexpr int NXC_CHUNK = 128;      // packets claimed from the global queue per atomic
+constexpr int NXC_BLOCK = 256;      // threads per workgroup of the flat kernels (4 waves)
+// The persistent kernels run ONE 12-wave workgroup per CU (3 waves per SIMD, <= 168 VGPRs): the
+// waves of a workgroup share a single LDS copy of the tables (~76 KB for Na with a 512^2 image),
+// which leaves room for the per-wave packet staging blocks inside the CU's 160 KB.
+constexpr int NXC_BLOCK_PERSIST = 768;
+constexpr int NXC_CHUNK = 64;       // packets claimed from the global queue per atomic (one per lane)
+constexpr int NXC_WAVE_STAGE_BYTES = NXC_CHUNK * 8 * 8;   // per-wave LDS staging of a claimed chunk
 
 // Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS.
 NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
@@ -86,7 +91,7 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
         double s[8], d[8];
 #pragma unroll
         for (int c = 0; c < 8; c++) s[c] = in[c * n + i];
-        rk5_step<DELTA>(F, T, s, hstep[i], d);
+        rk5_step<DELTA, false>(F, T, s, hstep[i], StepW{}, d);
 #pragma unroll
         for (int c = 0; c < 8; c++) out[c * n + i] = s[c];
         if (DELTA) {
@@ -101,8 +106,8 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
 // like the reference's `results` (Output.py:376).
 template <bool IMAGE>
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_const_traj(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes,
-             int64_t n, const double *__restrict__ soa0, double step, int64_t n_iter,
+k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
+             int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t n_iter,
              double outeredge, double *__restrict__ traj, int64_t nrec,
              double *__restrict__ final_out, long long *__restrict__ steps_out,
              double *__restrict__ image, unsigned long long *__restrict__ counts,
@@ -121,12 +126,12 @@ k_const_traj(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t
         bool alive = s[7] > 0.0;
         if (IMAGE && alive) {
             my_samples++;
-            my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+            my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
                                       my_nonfinite);
         }
         long long k = 0;
         while (alive && k < n_iter) {
-            rk5_step<false>(F, T, s, step, d);
+            rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
             apply_fate<false>(s, outeredge);
             k++; my_steps++;
             if (k < nrec) {
@@ -136,7 +141,7 @@ k_const_traj(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t
             alive = s[7] > 0.0;
             if (IMAGE && alive) {
                 my_samples++;
-                my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
                                           my_nonfinite);
             }
         }
@@ -155,15 +160,20 @@ k_const_traj(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-level packet queue: lanes without a packet are served from the wave's current chunk
-// [c_next, c_end) in lane order (prefix rank over the ballot); an exhausted chunk is replaced by
-// one atomicAdd of NXC_CHUNK on the global head.  All control flow here is wave-uniform.
-// Returns the packet index for this lane or -1.
+// Wave-level packet queue.  A wave claims NXC_CHUNK consecutive packet indices with one atomicAdd
+// on the global head and immediately copies their 8 state columns into its own LDS staging block
+// (coalesced: lane l loads packet base+l).  Lanes whose packet has died are then served from that
+// block in lane order (prefix rank over the ballot) with LDS reads only, so the steady-state loop
+// contains no global load and never has to wait (in-order vmcnt) behind its own in-flight image
+// atomics.  All control flow here is wave-uniform.  Returns the packet index or -1; on success
+// the lane's state is in s[].
 struct WaveQueue {
-    long long c_next = 0, c_end = 0;
+    long long c_base = 0;
+    int c_pos = 0, c_cnt = 0;
     bool drained = false;
 
-    NXC_DEV long long refill(bool need, unsigned long long *head, long long n)
+    NXC_DEV long long refill(bool need, unsigned long long *head, long long n,
+                             const double *__restrict__ soa0, int stage_off, double (&s)[8])
     {
         const unsigned long long mask = __ballot(need);
         long long mine = -1;
@@ -171,20 +181,34 @@ struct WaveQueue {
         const int want = __popcll(mask);
         const int lane = threadIdx.x & 63;
         const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        double *stage = reinterpret_cast<double *>(nxc_lds + stage_off);
         int served = 0;
         while (served < want) {
-            if (c_next >= c_end) {
+            if (c_pos >= c_cnt) {
                 long long b = 0;
                 if (lane == 0) b = (long long)atomicAdd(head, (unsigned long long)NXC_CHUNK);
                 b = wave_bcast0(b);
                 if (b >= n) { drained = true; break; }
-                c_next = b;
-                c_end = (b + NXC_CHUNK < n) ? b + NXC_CHUNK : n;
+                c_base = b;
+                c_cnt = (b + NXC_CHUNK <= n) ? NXC_CHUNK : (int)(n - b);
+                c_pos = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (lane < c_cnt) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) stage[c * NXC_CHUNK + lane] = soa0[c * n + b + lane];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            const long long room = c_end - c_next;
-            const int take = room < (long long)(want - served) ? (int)room : want - served;
-            if (need && rank >= served && rank < served + take) mine = c_next + (rank - served);
-            c_next += take;
+            const int room = c_cnt - c_pos;
+            const int take = room < (want - served) ? room : want - served;
+            if (need && rank >= served && rank < served + take) {
+                const int slot = c_pos + (rank - served);
+                mine = c_base + slot;
+#pragma unroll
+                for (int c = 0; c < 8; c++) s[c] = stage[c * NXC_CHUNK + slot];
+            }
+            c_pos += take;
             served += take;
         }
         return mine;
@@ -195,9 +219,9 @@ struct WaveQueue {
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
 template <bool IMAGE>
-__global__ void __launch_bounds__(NXC_BLOCK)
-k_const_fused(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes,
-              int64_t n, const double *__restrict__ soa0, double step, int64_t n_iter,
+__global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
+k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
+              int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t n_iter,
               double outeredge, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ image,
               unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr)
@@ -206,18 +230,17 @@ k_const_fused(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_
     const LutView T = lut_view(F.tab);
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     WaveQueue q;
+    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
     bool has = false;
     long long id = -1, k = 0;
     double s[8], d[8];
     for (;;) {
-        const long long got = q.refill(!has, &ctr->queue_head, n);
+        const long long got = q.refill(!has, &ctr->queue_head, n, soa0, stage_off, s);
         if (got >= 0) {
             id = got; k = 0; has = true;
-#pragma unroll
-            for (int c = 0; c < 8; c++) s[c] = soa0[c * n + id];
             if (IMAGE && s[7] > 0.0) {
                 my_samples++;
-                my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
                                           my_nonfinite);
             }
         }
@@ -225,13 +248,13 @@ k_const_fused(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_
         if (has) {
             bool done = !(s[7] > 0.0) || k >= n_iter;
             if (!done) {
-                rk5_step<false>(F, T, s, step, d);
+                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
                 apply_fate<false>(s, outeredge);
                 k++; my_steps++;
                 if (s[7] > 0.0) {
                     if (IMAGE) {
                         my_samples++;
-                        my_binned += image_sample(G, s[1], s[2], s[3], s[5], s[7], image,
+                        my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image,
                                                   counts, my_nonfinite);
                     }
                     done = k >= n_iter;
@@ -265,7 +288,7 @@ k_const_fused(ForceK F, ImageK G, const unsigned char *__restrict__ blob, int64_
 //   errmax < 1e-7 -> errmax = 1 and h*10, which lands in the REJECT branch (errmax >= 1)  :294-300
 //   accept (errmax < 1): fate tests on r^2; the grown step is never stored  :302-327
 //   reject: stored step = max(0.95 h errmax^-0.25, 0.1 h)               :333-342
-__global__ void __launch_bounds__(NXC_BLOCK)
+__global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
       const double *__restrict__ soa0, double resolution, double outeredge, long long max_steps,
       double *__restrict__ final_out, double *__restrict__ hstore_out,
@@ -276,15 +299,14 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
     unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
     WaveQueue q;
+    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
     bool has = false;
     long long id = -1, it = 0;
     double s[8], hs = 1000.0;
     for (;;) {
-        const long long got = q.refill(!has, &ctr->queue_head, n);
+        const long long got = q.refill(!has, &ctr->queue_head, n, soa0, stage_off, s);
         if (got >= 0) {
             id = got; it = 0; hs = 1000.0; has = true;
-#pragma unroll
-            for (int c = 0; c < 8; c++) s[c] = soa0[c * n + id];
         }
         if (__ballot(has) == 0) break;
         if (has) {
@@ -297,7 +319,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                     double t[8], d[8];
 #pragma unroll
                     for (int c = 0; c < 8; c++) t[c] = s[c];
-                    rk5_step<true>(F, T, t, h, d);
+                    rk5_step<true, false>(F, T, t, h, StepW{}, d);
                     my_steps++; it++;
                     const double fscale = resf + __builtin_fabs(t[7]) * resf;
                     double e = d[0];
@@ -343,7 +365,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_image(ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
+k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
         const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
         const double *__restrict__ vy, const double *__restrict__ frac,
         double *__restrict__ image, unsigned long long *__restrict__ counts,
@@ -354,7 +376,7 @@ k_image(ImageK G, const unsigned char *__restrict__ blob, int64_t stage_bytes, i
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p;
          i += (int64_t)gridDim.x * blockDim.x) {
         my_samples++;
-        my_binned += image_sample(G, x[i], y[i], z[i], vy[i], frac[i], image, counts,
+        my_binned += image_sample(lds_header().G, x[i], y[i], z[i], vy[i], frac[i], image, counts,
                                   my_nonfinite);
     }
     flush_counter(&ctr->samples, my_samples);
