@@ -74,26 +74,32 @@ NXC_DEV LutView lut_view(const LutDesc &d)
     return v;
 }
 
-NXC_DEV double lut_interp(const LutView &t, double x)
+NXC_DEV double lut_interp(const LutView &t, double xin)
 {
-    if (x != x) return x;
-    if (x > t.xlast) return t.f_last;
-    if (x < t.x0) return t.f_first;
+    // Clamping to [x0, xlast] reproduces np.interp's end values exactly: at x0 record 0 gives
+    // slope*0 + fp[0]; the last record has slope 0.
+    double x = xin < t.x0 ? t.x0 : xin;
+    x = x > t.xlast ? t.xlast : x;
     int c = (int)((x - t.x0) * t.inv_w);
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
     const int j1 = j + 1 < t.n ? j + 1 : t.n - 1;
-    LutRec r = lds_rec(t.rec + 32 * j);
+    const LutRec r0 = lds_rec(t.rec + 32 * j);
     const LutRec r1 = lds_rec(t.rec + 32 * j1);
-    const bool in0 = (x >= r.xp) && (x < r.xn);
+    const bool in0 = (x >= r0.xp) && (x < r0.xn);
     const bool in1 = (x >= r1.xp) && (x < r1.xn);
-    if (!in0) r = r1;
-    if (!(in0 || in1)) {                       // rare: walk to the interval
+    LutRec r;
+    r.xp = in0 ? r0.xp : r1.xp;
+    r.fp = in0 ? r0.fp : r1.fp;
+    r.sl = in0 ? r0.sl : r1.sl;
+    if (__builtin_expect(!(in0 || in1), 0)) {  // rare: walk to the interval
         while (j > 0 && x < lds_f64(t.rec + 32 * j)) --j;
         while (x >= lds_f64(t.rec + 32 * j + 24)) ++j;
-        r = lds_rec(t.rec + 32 * j);
+        const LutRec rw = lds_rec(t.rec + 32 * j);
+        r.xp = rw.xp; r.fp = rw.fp; r.sl = rw.sl;
     }
-    return r.sl * (x - r.xp) + r.fp;
+    const double v = r.sl * (x - r.xp) + r.fp;
+    return xin != xin ? xin : v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -120,10 +126,16 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
 {
     double gx = 0.0, gy = 0.0, gz = 0.0;
     if (F.grav) {                                         // state.py:19-21
-        double r3 = nxc_cube(__builtin_sqrt((x * x + y * y) + z * z));
-        gx = F.GM * x / r3;
-        gy = F.GM * y / r3;
-        gz = F.GM * z / r3;
+        const double r3 = nxc_cube(nxc_sqrt((x * x + y * y) + z * z));
+        const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
+        if (nxc_mid_range(r3)) {                          // one refined reciprocal, three quotients
+            const double rinv = nxc_recip_seed(r3);
+            gx = nxc_div_seeded(nx, r3, rinv);
+            gy = nxc_div_seeded(ny, r3, rinv);
+            gz = nxc_div_seeded(nz, r3, rinv);
+        } else {
+            gx = nx / r3; gy = ny / r3; gz = nz / r3;
+        }
     }
     const bool lit = sunlit(x, y, z);
     double ry = 0.0;
@@ -131,9 +143,9 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
         double vv = vy + F.vrplanet;
         ry = lut_interp(T, vv) * (lit ? 1.0 : 0.0);
     }
-    ax = gx + 0.0;                                        // state.py:41
+    ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
     ay = gy + ry;
-    az = gz + 0.0;
+    az = gz;
     if (F.loss == LOSS_LIFETIME) ion = F.inv_lifetime;    // state.py:44-46
     else if (F.loss == LOSS_PHOTO) ion = F.photo * (lit ? 1.0 : 0.0);   // state.py:48-52
     else ion = 0.0;
@@ -181,9 +193,17 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
     for (int n = 0; n < 6; n++) {
         kv[n][0] = vx; kv[n][1] = vy; kv[n][2] = vz;
         state_eval(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
-        double nx = 0.0, ny = 0.0, nz = 0.0, nvx = 0.0, nvy = 0.0, nvz = 0.0, nlf = 0.0;
+        // The reference starts each sum from 0.0 (0 + t0): dropped, it can only change the sign
+        // of an exactly-zero sum.
+        double nx, ny, nz, nvx, nvy, nvz, nlf;
+        {
+            const double w = UNIFORM_H ? W.w[n * (n + 1) / 2] : h * Tableau::A[n + 1][0];
+            nx = w * kv[0][0]; ny = w * kv[0][1]; nz = w * kv[0][2];
+            nvx = w * ka[0][0]; nvy = w * ka[0][1]; nvz = w * ka[0][2];
+            nlf = -(w * kl[0]);
+        }
 #pragma unroll
-        for (int i = 0; i <= n; i++) {
+        for (int i = 1; i <= n; i++) {
             const double w = UNIFORM_H ? W.w[n * (n + 1) / 2 + i] : h * Tableau::A[n + 1][i];
             nx += w * kv[i][0];
             ny += w * kv[i][1];
@@ -226,7 +246,7 @@ template <bool R_SQUARED>
 NXC_DEV void apply_fate(double (&s)[8], double outeredge)
 {
     double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
-    double rr = R_SQUARED ? r2 : __builtin_sqrt(r2);
+    double rr = R_SQUARED ? r2 : nxc_sqrt(r2);
     if (r2 < 1.0) s[7] = 0.0;
     if (rr > outeredge) s[7] = 0.0;
     if (s[7] < 1e-10) s[7] = 0.0;
@@ -301,9 +321,9 @@ NXC_DEV int image_sample(const ImageK &G, double x, double y, double z,
 #pragma unroll
         for (int l = 0; l < 4; l++)
             if (l < G.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
-        w = frac * (sunlit(x, y, z) ? 1.0 : 0.0) * gg / 1e6;
+        w = nxc_div(frac * (sunlit(x, y, z) ? 1.0 : 0.0) * gg, 1e6);
     }
-    w = w / G.apix_cm2;                                            // ModelImage.py:262
+    w = nxc_div(w, G.apix_cm2);                                    // ModelImage.py:262
     if (!(__builtin_fabs(w) <= 1.7976931348623157e308)) nonfinite++;   // ModelResult.py:170
     const int ix = bin_index(xo, (int)G.xedges_off, G.nx, G.x_lo, G.x_inv_step);
     const int iz = bin_index(zo, (int)G.zedges_off, G.nz, G.z_lo, G.z_inv_step);

@@ -325,11 +325,11 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                     double e = d[0];
 #pragma unroll
                     for (int c = 1; c <= 3; c++)
-                        e = __builtin_fmax(e, d[c] / (resx + __builtin_fabs(t[c]) * resx));
+                        e = __builtin_fmax(e, nxc_div(d[c], resx + __builtin_fabs(t[c]) * resx));
 #pragma unroll
                     for (int c = 4; c <= 6; c++)
-                        e = __builtin_fmax(e, d[c] / (resv + __builtin_fabs(t[c]) * resv));
-                    e = __builtin_fmax(e, d[7] / fscale);
+                        e = __builtin_fmax(e, nxc_div(d[c], resv + __builtin_fabs(t[c]) * resv));
+                    e = __builtin_fmax(e, nxc_div(d[7], fscale));
                     if (!(__builtin_fabs(e) <= 1.7976931348623157e308)) { my_nonfinite++; done = true; }
                     else {
                         if (t[7] < 0.0 && e < 1.0) my_neg++;
@@ -395,8 +395,8 @@ __global__ void k_math(int which, int64_t n, const double *__restrict__ in,
         case 0: r = nxc_exp(v); break;
         case 1: r = nxc_log(v); break;
         case 2: r = nxc_cube(v); break;
-        case 3: r = __builtin_sqrt(v); break;
-        default: r = v / in2[i]; break;
+        case 3: r = nxc_sqrt(v); break;
+        default: r = nxc_div(v, in2[i]); break;
         }
         out[i] = r;
     }

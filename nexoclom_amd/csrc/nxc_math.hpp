@@ -19,6 +19,59 @@
 
 #define NXC_DEV __device__ __forceinline__
 
+// --- correctly rounded sqrt and division without the range-scaling wrapper ------------------------
+// hipcc expands fp64 sqrt and '/' into v_rsq_f64 / v_rcp_f64 + a fixed Newton/fma chain, wrapped in
+// v_ldexp / v_div_scale / v_div_fixup steps that only act when an operand is near the ends of the
+// exponent range.  Positions, speeds and GM of this problem sit within 2^+-200, so the wrappers are
+// dead weight in a VALU-bound kernel.  These helpers run the SAME fma chains (so they return the
+// same, correctly rounded, bits; checked against NumPy on the GPU in tests/test_gpu_parity.py)
+// and fall back to the compiler's full sequence outside that range.  A reciprocal refined once is
+// shared by the three quotients of the gravity term.
+NXC_DEV bool nxc_mid_range(double a)
+{
+    const double m = __builtin_fabs(a);
+    return (m > 0x1p-200) && (m < 0x1p+200);
+}
+
+NXC_DEV double nxc_sqrt(double x)
+{
+    if (!nxc_mid_range(x)) return __builtin_sqrt(x);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    return __builtin_fma(d1, h, g);
+}
+
+// 1/d refined by two Newton steps (the y of the division chain below)
+NXC_DEV double nxc_recip_seed(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+
+// n/d given y = nxc_recip_seed(d); both operands in the middle exponent range
+NXC_DEV double nxc_div_seeded(double n, double d, double y)
+{
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+}
+
+NXC_DEV double nxc_div(double n, double d)
+{
+    if (!(nxc_mid_range(d) && (nxc_mid_range(n) || n == 0.0))) return n / d;
+    return nxc_div_seeded(n, d, nxc_recip_seed(d));
+}
+
 NXC_DEV double nxc_cube(double r)
 {
     double sq = r * r;
@@ -54,8 +107,8 @@ NXC_DEV double nxc_exp(double x)
     }
     double t = x * x;
     double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
-    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k == 0) return 1.0 - (nxc_div(x * c, c - 2.0) - x);
+    double y = 1.0 - ((lo - nxc_div(x * c, 2.0 - c)) - hi);
     if (k >= -1021)
         return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
     return __longlong_as_double(__double_as_longlong(y) + ((long long)(k + 1000) << 52))
@@ -89,7 +142,7 @@ NXC_DEV double nxc_log(double x)
         double R = f * f * (0.5 - 0.33333333333333333 * f);
         return k == 0 ? f - R : dk * LN2_HI - ((R - dk * LN2_LO) - f);
     }
-    double s = f / (2.0 + f), z = s * s, w = z * z;
+    double s = nxc_div(f, 2.0 + f), z = s * s, w = z * z;
     double t1 = w * (L2 + w * (L4 + w * L6));
     double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
     double R = t2 + t1;
@@ -103,4 +156,4 @@ NXC_DEV double nxc_log(double x)
     return k == 0 ? f - s * (f - R) : dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
 }
 
-NXC_DEV double nxc_pow_m025(double e) { return 1.0 / __builtin_sqrt(__builtin_sqrt(e)); }
+NXC_DEV double nxc_pow_m025(double e) { return nxc_div(1.0, nxc_sqrt(nxc_sqrt(e))); }

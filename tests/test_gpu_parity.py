@@ -17,10 +17,20 @@ pytestmark = pytest.mark.gpu
 
 def test_device_math_is_ieee_exact(ctx, coracle):
     rng = np.random.default_rng(0)
-    x = rng.uniform(1e-3, 1e3, 400000)
-    y = rng.uniform(1e-3, 1e3, 400000)
-    assert np.array_equal(ctx.math('sqrt', x), np.sqrt(x))
-    assert np.array_equal(ctx.math('div', x, y), x/y)
+    # nxc_sqrt / nxc_div (the streamlined chains the kernels use) must stay correctly rounded:
+    # operational range, wide range, and beyond +-2^200 where they fall back to the full sequence
+    for lo, hi, n in ((-3, 3, 2000000), (-60, 60, 1000000), (-300, 300, 400000)):
+        x = 10**rng.uniform(lo, hi, n)*rng.choice([1.0, 1.0, 0.999999], n)
+        y = 10**rng.uniform(lo/2, hi/2, n)*rng.choice([-1.0, 1.0], n)
+        assert np.array_equal(ctx.math('sqrt', x), np.sqrt(x))
+        with np.errstate(over='ignore', under='ignore'):
+            assert np.array_equal(ctx.math('div', x, y), x/y)
+    m = 1 + rng.integers(0, 2**52, 1000000)*2.0**-52        # dense mantissas
+    assert np.array_equal(ctx.math('sqrt', m), np.sqrt(m))
+    assert np.array_equal(ctx.math('sqrt', 2*m), np.sqrt(2*m))
+    d = 1 + rng.integers(0, 2**52, 1000000)*2.0**-52
+    assert np.array_equal(ctx.math('div', m, d), m/d)
+    assert np.array_equal(ctx.math('div', np.zeros(8), d[:8]), np.zeros(8))
     r = rng.uniform(0.5, 40, 400000)
     assert np.array_equal(ctx.math('cube', r), coracle.math('cube', r))
     e = -rng.uniform(0, 40, 400000)
