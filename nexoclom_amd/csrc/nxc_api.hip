@@ -172,6 +172,9 @@ struct nxc_handle {
     double *d_packets = nullptr;
     size_t packets_cap = 0;
     int64_t n_packets = 0;
+    unsigned *d_order = nullptr;     // packet indices by decreasing launch speed (queue order)
+    size_t order_cap = 0;
+    bool have_order = false;
     DevCounters *d_ctr = nullptr;
     double *d_scratch = nullptr;     // final states / generic device scratch
     size_t scratch_cap = 0;
@@ -311,7 +314,8 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<true>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
                            h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           n_iter, outeredge, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter, outeredge,
+                           d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
     } else {
         if ((rc = prep_kernel(k_const_fused<false>, lds))) return rc;
         if ((rc = persistent_grid(h, k_const_fused<false>, BLOCK_PERSIST, lds, h->n_packets,
@@ -320,7 +324,8 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<false>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
                            h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           n_iter, outeredge, d_final, d_steps, (double *)nullptr,
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter, outeredge,
+                           d_final, d_steps, (double *)nullptr,
                            (unsigned long long *)nullptr, h->d_ctr);
     }
     HIPCHK(hipGetLastError());
@@ -388,7 +393,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
-                    h->d_steps, h->d_reduce};
+                    h->d_steps, h->d_reduce, h->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -618,6 +623,42 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
     if (rc) return rc;
     if (n) HIPCHK(hipMemcpyAsync(h->d_packets, soa0, bytes, hipMemcpyHostToDevice, h->stream));
+    // Queue order for the persistent kernels: counting sort of the packet indices by decreasing
+    // |v|^2 (4096 bins).  Fast packets live longest (escape to outeredge / bound orbits).
+    h->have_order = false;
+    if (n > 1 && n < (int64_t)0xffffffffll) {
+        std::vector<float> key((size_t)n);
+        float kmax = 0.f;
+        for (int64_t i = 0; i < n; i++) {
+            const double vx = soa0[4 * n + i], vy = soa0[5 * n + i], vz = soa0[6 * n + i];
+            const float k = (float)(vx * vx + vy * vy + vz * vz);
+            key[(size_t)i] = k;
+            if (k > kmax) kmax = k;
+        }
+        if (kmax > 0.f && std::isfinite(kmax)) {
+            constexpr int NB = 4096;
+            const float scale = (float)(NB - 1) / kmax;
+            std::vector<int64_t> start(NB + 1, 0);
+            std::vector<unsigned short> bin((size_t)n);
+            for (int64_t i = 0; i < n; i++) {
+                const float f = key[(size_t)i] * scale;
+                int b = (f >= 0.f && f < (float)NB) ? (int)f : 0;
+                b = NB - 1 - b;                                  // descending speed
+                bin[(size_t)i] = (unsigned short)b;
+                start[b + 1]++;
+            }
+            for (int b = 0; b < NB; b++) start[b + 1] += start[b];
+            std::vector<unsigned> order((size_t)n);
+            for (int64_t i = 0; i < n; i++) order[(size_t)start[bin[(size_t)i]]++] = (unsigned)i;
+            rc = ensure(reinterpret_cast<void **>(&h->d_order), &h->order_cap,
+                        (size_t)n * sizeof(unsigned));
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(h->d_order, order.data(), (size_t)n * sizeof(unsigned),
+                                  hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->have_order = true;
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->n_packets = n;
     return NXC_OK;
@@ -737,7 +778,8 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     if ((rc = persistent_grid(h, k_var, BLOCK_PERSIST, lds, n, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_var, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)h->force_bytes, n, h->d_packets, resolution, outeredge, (long long)max_steps,
+                       (int64_t)h->force_bytes, n, h->d_packets,
+                       h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge, (long long)max_steps,
                        d_final, d_hs, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
