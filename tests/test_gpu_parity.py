@@ -166,3 +166,28 @@ def test_variable_driver_bit_exact(ctx, coracle):
     ctr = ctx.counters()
     assert ctr['particle_steps'] == work
     assert ctr['bad_step'] == ctr['nonfinite'] == ctr['neg_frac'] == ctr['unfinished'] == 0
+
+
+def test_rccl_single_rank_allreduce(ctx, coracle):
+    """The RCCL path (dlopen librccl, communicator, fp64 + u64 all-reduce on the handle's stream)
+    with a world of one: the image pair must come back unchanged."""
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    X0 = H.sample_x0(5000, 3, 50000.)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    im = H.image_setup(f, 'radiance', dims=(64, 64))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'])
+    ctx.upload_packets(X0)
+    ctx.integrate_const(30., n_iter, 25., image=True)
+    image0, counts0 = ctx.image_download()
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 0, 1)
+    ctx.image_allreduce()
+    ctx.barrier()
+    assert ctx.allreduce_max(3.25) == 3.25
+    image1, counts1 = ctx.image_download()
+    ctx.comm_destroy()
+    assert np.array_equal(image0, image1) and np.array_equal(counts0, counts1)
+    assert counts0.sum() > 0
