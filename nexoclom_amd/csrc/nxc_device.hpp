@@ -281,16 +281,52 @@ NXC_DEV const LdsHeader &lds_header()
     return *reinterpret_cast<const LdsHeader *>(nxc_lds);
 }
 
-// np.histogram2d bin along one axis: searchsorted(edges, v, 'right') - 1, the right-most edge
-// folded into the last bin, everything else (NaN included) outside = -1.  The arithmetic guess
-// is corrected against the very edge values np.linspace produced (staged in LDS).
-NXC_DEV int bin_index(double v, int edges, int n, double lo, double inv_step)
+// Launch constants of the image path that are worth a register: read from the LDS header once
+// per thread before the step loop (the compiler cannot hoist LDS loads over the loop's LDS
+// stores).  The two refined reciprocals serve the per-sample divisions by 1e6 and by Apix.
+struct ImageRegs {
+    double vrplanet, rs_1e6, rs_apix, apix;
+    double x_lo, x_hi, x_inv_step, z_lo, z_hi, z_inv_step;
+    int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg;
+};
+
+NXC_DEV ImageRegs image_regs(const ImageK &G)
 {
-    if (!(v >= lds_f64(edges)) || !(v <= lds_f64(edges + 8 * n))) return -1;
+    ImageRegs R;
+    R.vrplanet = G.vrplanet;
+    R.apix = G.apix_cm2;
+    R.rs_1e6 = nxc_recip_seed(1e6);
+    R.rs_apix = nxc_recip_seed(G.apix_cm2);
+    R.xedges = (int)G.xedges_off; R.zedges = (int)G.zedges_off;
+    R.nx = G.nx; R.nz = G.nz;
+    R.x_lo = lds_f64(R.xedges); R.x_hi = lds_f64(R.xedges + 8 * R.nx);
+    R.z_lo = lds_f64(R.zedges); R.z_hi = lds_f64(R.zedges + 8 * R.nz);
+    R.x_inv_step = G.x_inv_step; R.z_inv_step = G.z_inv_step;
+    R.quantity = G.quantity; R.n_lines = G.n_lines; R.downcast = G.downcast_f32; R.dbg = G.dbg;
+    return R;
+}
+
+// n/d for a launch-constant d with y = nxc_recip_seed(d) precomputed: same bits as nxc_div(n, d).
+NXC_DEV double nxc_div_const(double n, double d, double y)
+{
+    if (!(nxc_mid_range(d) && (nxc_mid_range(n) || n == 0.0))) return n / d;
+    return nxc_div_seeded(n, d, y);
+}
+
+// np.histogram2d bin along one axis: searchsorted(edges, v, 'right') - 1, the right-most edge
+// folded into the last bin, everything else (NaN included) outside = -1.  The arithmetic guess is
+// verified against the very edge values np.linspace produced (staged in LDS, one ds_read2_b64);
+// only a sample within rounding of an edge takes the walk.
+NXC_DEV int bin_index(double v, int edges, int n, double lo, double hi, double inv_step)
+{
+    if (!(v >= lo) || !(v <= hi)) return -1;
     int k = (int)((v - lo) * inv_step);
-    k = k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
-    while (k > 0 && v < lds_f64(edges + 8 * k)) --k;
-    while (k < n - 1 && v >= lds_f64(edges + 8 * (k + 1))) ++k;
+    k = k > n - 1 ? n - 1 : k;
+    const double e0 = lds_f64(edges + 8 * k), e1 = lds_f64(edges + 8 * k + 8);
+    if (__builtin_expect(!((v >= e0) && (v < e1)), 0)) {
+        while (k > 0 && v < lds_f64(edges + 8 * k)) --k;
+        while (k < n - 1 && v >= lds_f64(edges + 8 * (k + 1))) ++k;
+    }
     return k;
 }
 
@@ -298,39 +334,45 @@ NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 
 // Adds one sample to the image pair.  Returns 1 if the sample fell inside the image.
 // The fp64 add is the hardware global_atomic_add_f64; counts are 64-bit integer atomics.
-NXC_DEV int image_sample(const ImageK &G, double x, double y, double z,
+// Samples outside the image skip the weight (only its finiteness assert is kept: the weight is
+// finite iff frac and the radial velocity are).
+NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y, double z,
                          double vy, double frac, double *image, unsigned long long *counts,
                          unsigned long long &nonfinite)
 {
-    if (G.downcast_f32) {
+    if (R.downcast) {
         x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
         vy = f32_round_trip(vy); frac = f32_round_trip(frac);
     }
-    const double radvel = vy + G.vrplanet;                         // ModelImage.py:242-243
+    const double radvel = vy + R.vrplanet;                         // ModelImage.py:242-243
     const double xo = (G.M[0] * x + G.M[1] * y) + G.M[2] * z;      // ModelImage.py:249
     const double yo = (G.M[3] * x + G.M[4] * y) + G.M[5] * z;
     const double zo = (G.M[6] * x + G.M[7] * y) + G.M[8] * z;
+    const int ix = bin_index(xo, R.xedges, R.nx, R.x_lo, R.x_hi, R.x_inv_step);
+    const int iz = bin_index(zo, R.zedges, R.nz, R.z_lo, R.z_hi, R.z_inv_step);
+    if (ix < 0 || iz < 0) {
+        if (!(__builtin_fabs(frac) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;
+        return 0;
+    }
     const double s_obs = xo * xo + zo * zo;                        // ModelImage.py:252-254
     const bool inview = (s_obs > 0x1.0000000000001p+0) || (yo < 0.0);
-    frac = frac * (inview ? 1.0 : 0.0);
+    frac = inview ? frac : frac * 0.0;
     double w;
-    if (G.quantity == 0) {                                         // ModelResult.py:148-149
+    if (R.quantity == 0) {                                         // ModelResult.py:148-149
         w = frac;
     } else {                                                       // ModelResult.py:150-161
-        double gg = 0.0;
+        double gg = R.n_lines > 0 ? lut_interp(lut_view(G.line[0]), radvel) : 0.0;
 #pragma unroll
-        for (int l = 0; l < 4; l++)
-            if (l < G.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
-        w = nxc_div(frac * (sunlit(x, y, z) ? 1.0 : 0.0) * gg, 1e6);
+        for (int l = 1; l < 4; l++)
+            if (l < R.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
+        const double lit = sunlit(x, y, z) ? frac : frac * 0.0;
+        w = nxc_div_const(lit * gg, 1e6, R.rs_1e6);
     }
-    w = nxc_div(w, G.apix_cm2);                                    // ModelImage.py:262
+    w = nxc_div_const(w, R.apix, R.rs_apix);                       // ModelImage.py:262
     if (!(__builtin_fabs(w) <= 1.7976931348623157e308)) nonfinite++;   // ModelResult.py:170
-    const int ix = bin_index(xo, (int)G.xedges_off, G.nx, G.x_lo, G.x_inv_step);
-    const int iz = bin_index(zo, (int)G.zedges_off, G.nz, G.z_lo, G.z_inv_step);
-    if (ix < 0 || iz < 0) return 0;
-    const int64_t pix = (int64_t)ix * G.nz + iz;
-    if (G.dbg == 1) return 1;
-    if (w != 0.0 && G.dbg != 3) unsafeAtomicAdd(&image[pix], w);
-    if (G.dbg != 2) atomicAdd(&counts[pix], 1ull);
+    const int64_t pix = (int64_t)ix * R.nz + iz;
+    if (R.dbg == 1) return 1;
+    if (w != 0.0 && R.dbg != 3) unsafeAtomicAdd(&image[pix], w);
+    if (R.dbg != 2) atomicAdd(&counts[pix], 1ull);
     return 1;
 }

@@ -115,6 +115,8 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
 {
     stage_tables(blob, stage_bytes);
     const LutView T = lut_view(F.tab);
+    ImageRegs IR{};
+    if (IMAGE) IR = image_regs(lds_header().G);
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -126,7 +128,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         bool alive = s[7] > 0.0;
         if (IMAGE && alive) {
             my_samples++;
-            my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
+            my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
                                       my_nonfinite);
         }
         long long k = 0;
@@ -141,7 +143,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
             alive = s[7] > 0.0;
             if (IMAGE && alive) {
                 my_samples++;
-                my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
                                           my_nonfinite);
             }
         }
@@ -236,6 +238,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 {
     stage_tables(blob, stage_bytes);
     const LutView T = lut_view(F.tab);
+    ImageRegs IR{};
+    if (IMAGE) IR = image_regs(lds_header().G);
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     WaveQueue q;
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
@@ -248,7 +252,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             id = got; k = 0; has = true;
             if (IMAGE && s[7] > 0.0) {
                 my_samples++;
-                my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image, counts,
+                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
                                           my_nonfinite);
             }
         }
@@ -262,7 +266,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 if (s[7] > 0.0) {
                     if (IMAGE) {
                         my_samples++;
-                        my_binned += image_sample(lds_header().G, s[1], s[2], s[3], s[5], s[7], image,
+                        my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image,
                                                   counts, my_nonfinite);
                     }
                     done = k >= n_iter;
@@ -380,11 +384,12 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
         DevCounters *__restrict__ ctr)
 {
     stage_tables(blob, stage_bytes);
+    const ImageRegs IR = image_regs(lds_header().G);
     unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p;
          i += (int64_t)gridDim.x * blockDim.x) {
         my_samples++;
-        my_binned += image_sample(lds_header().G, x[i], y[i], z[i], vy[i], frac[i], image, counts,
+        my_binned += image_sample(lds_header().G, IR, x[i], y[i], z[i], vy[i], frac[i], image, counts,
                                   my_nonfinite);
     }
     flush_counter(&ctr->samples, my_samples);
