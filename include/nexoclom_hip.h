@@ -15,6 +15,7 @@
  *                          + ModelResult.packet_weighting()       data_simulation/ModelResult.py:140-170
  *                          + Histogram2d()                        math/histogram.py:28-39
  *   nxc_image_allreduce    the per-output-file image sum          data_simulation/ModelImage.py:96-98
+ *   nxc_los_accumulate     compute_iteration() inner work          data_simulation/compute_iteration.py:138-217
  *
  * Conventions
  *   - Every function returns 0 on success or a negative nxc_status; nothing is thrown across the
@@ -158,6 +159,39 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
  * Adds to the resident image pair (use nxc_image_clear / nxc_image_download around it). */
 int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
                          const double *z, const double *vy, const double *frac);
+
+/* ---- f-1: spacecraft line-of-sight cones ----------------------------------------------------------
+ * For each of S spectra (spacecraft position + boresight) sum weight/Apix over the stored samples
+ * inside the view cone of half-angle dphi, in front of the planet cut-off, that the reference's
+ * KD-tree ball pre-selection would have offered (compute_iteration.py:164-185), with the shadow test
+ * at the line-of-sight foot point (:202-206).  All angles/trig values are computed by the caller
+ * (NumPy) so that thresholds are the reference's own:
+ *   sc            host [8][S]: x, y, z, xbore, ybore, zbore, dist_from_plan (1e30 if the LOS misses
+ *                 the planet, :105-115), ladder length K_i (as a double)
+ *   ladder        t_k = t_{k-1} (1 + sin dphi), t_0 = sin dphi, the longest of the S ladders (:164-167)
+ *   cos_threshold smallest double c with arccos(c) <= dphi
+ * Outputs: radiance[S] (fp64 sum), npackets[S], included[n_index] (nullable: set to 1 for every
+ * packet index seen in a cone, :191), used_pairs (nullable, [2][used_cap]: spectrum, sample row of
+ * every pair with weight > 0, :210) and *n_used (pairs found; may exceed used_cap). */
+typedef struct nxc_los_desc {
+    double dphi, sin_dphi, sin_2dphi, cos_threshold;
+    double vrplanet;      /* R/s                                                                   */
+    double unit_cm;       /* planet radius in cm: Apix = pi (d sin dphi)^2 unit_cm^2               */
+    int32_t n_lines;      /* g-value tables summed (radiance is the only quantity the reference has
+                             here, compute_iteration.py:198-213)                                   */
+    int32_t reserved;
+    int64_t line_n[NXC_MAX_LINES];
+    const double *line_v[NXC_MAX_LINES];
+    const double *line_g[NXC_MAX_LINES];
+    int64_t n_ladder;
+    const double *ladder;
+} nxc_los_desc;
+
+int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
+                       int64_t P, const double *x, const double *y, const double *z,
+                       const double *vy, const double *frac, const int64_t *index,
+                       int64_t n_index, double *radiance, int64_t *npackets, uint8_t *included,
+                       int64_t used_cap, int64_t *used_pairs, int64_t *n_used);
 
 /* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
  * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other

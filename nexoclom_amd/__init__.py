@@ -9,6 +9,7 @@ __version__ = '0.1.0'
 from .Input import Input                    # noqa: F401
 from .Output import Output                  # noqa: F401
 from .ModelImage import ModelImage, ModelResult   # noqa: F401
+from .LOSResult import LOSResult, SpacecraftData   # noqa: F401
 from .solarsystem import SSObject, planet_dist    # noqa: F401
 from .atomicdata import gValue, RadPresConst, PhotoRate, atomicmass   # noqa: F401
 from .input_classes import InputError       # noqa: F401

@@ -414,3 +414,107 @@ __global__ void k_math(int which, int64_t n, const double *__restrict__ in,
         out[i] = r;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Spacecraft line-of-sight cones (data_simulation/compute_iteration.py:98-232): for every
+// (stored sample, spectrum) pair decide whether the sample lies in the view cone of half-angle
+// dphi in front of the planet cut-off, and add its weight / Apix to that spectrum's radiance.
+// The reference narrows the pairs with a KD-tree (balls of radius t_k sin(2 dphi) around the ladder
+// points t_k along the line of sight); here all pairs are tested: a spectra tile sits in LDS and
+// is broadcast to the lanes, each lane owns samples.  The ball pre-selection is reproduced for
+// the (rare) pairs that pass the cone test, so the selected set is the reference's.
+struct LosK {
+    double sin_dphi, sin_2dphi, cos_thr, cos_thr2_lo, vrplanet, unit_cm2;
+    double log1p_s_inv, t0;        // ladder: t_k = t0 (1 + sin_dphi)^k; only to seed the ball search
+    int n_lines, n_ladder;
+    int64_t tile_off;              // byte offset of the spectra tile inside the LDS block
+    LutDesc line[4];
+};
+
+constexpr int NXC_LOS_TILE = 128;  // spectra per workgroup tile (8 doubles each)
+
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
+      const double *__restrict__ sc, int64_t P, const double *__restrict__ x,
+      const double *__restrict__ y, const double *__restrict__ z, const double *__restrict__ vy,
+      const double *__restrict__ frac, const long long *__restrict__ index,
+      const double *__restrict__ ladder, double *__restrict__ radiance,
+      unsigned long long *__restrict__ npackets, unsigned char *__restrict__ included,
+      long long used_cap, long long *__restrict__ used_pairs,
+      unsigned long long *__restrict__ n_used, DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);
+    const int64_t s0 = (int64_t)blockIdx.y * NXC_LOS_TILE;
+    const int ns = (int)((S - s0) < NXC_LOS_TILE ? (S - s0) : NXC_LOS_TILE);
+    double *tile = reinterpret_cast<double *>(nxc_lds + K.tile_off);
+    for (int w = threadIdx.x; w < ns * 8; w += blockDim.x) {
+        const int c = w / ns, j = w - c * ns;
+        tile[j * 8 + c] = sc[c * S + s0 + j];
+    }
+    __syncthreads();
+    const double rs_1e6 = nxc_recip_seed(1e6);
+    unsigned long long my_pairs = 0, my_nonfinite = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const double px = x[p], py = y[p], pz = z[p];
+        bool have_w = false;
+        double weight = 0.0;
+        for (int j = 0; j < ns; j++) {
+            const double xs = tile[j * 8 + 0], ys = tile[j * 8 + 1], zs = tile[j * 8 + 2];
+            const double bx = tile[j * 8 + 3], by = tile[j * 8 + 4], bz = tile[j * 8 + 5];
+            const double rx = px - xs, ry = py - ys, rz = pz - zs;
+            const double q = (rx * bx + ry * by) + rz * bz;           // losrad   :178
+            if (!(q > 0.0) || !(q < tile[j * 8 + 6])) continue;        // cone in front; planet cut :185
+            const double d2 = (rx * rx + ry * ry) + rz * rz;
+            if (!(q * q >= K.cos_thr2_lo * d2)) continue;              // coarse cone test
+            const double dist = nxc_sqrt(d2);                          // :177
+            double cosang = nxc_div(q, dist);                          // :179
+            cosang = cosang > 1.0 ? 1.0 : cosang;                      // :180
+            if (!(cosang >= K.cos_thr)) continue;                      // ang <= dphi  :181-185
+            // KD-tree pre-selection (:164-173): inside any ball |X - (x_sc + bore t_k)| <= t_k sin(2 dphi)
+            const int nk = (int)tile[j * 8 + 7];
+            int kc = (int)(nxc_log(q / K.t0) * K.log1p_s_inv);
+            kc = kc < 0 ? 0 : kc;
+            bool cand = false;
+            for (int k = kc - 3; k <= kc + 3; k++) {
+                if (k < 0 || k >= nk) continue;
+                const double t = ladder[k];
+                const double cx = xs + bx * t, cy = ys + by * t, cz = zs + bz * t;
+                const double ex = cx - px, ey = cy - py, ez = cz - pz;
+                const double r = t * K.sin_2dphi;
+                cand = cand || (((ex * ex + ey * ey) + ez * ez) <= r * r);
+            }
+            if (!cand) continue;
+            if (!have_w) {                                             // ModelResult.py:150-161, oos = 1
+                const double radvel = vy[p] + K.vrplanet;
+                double gg = K.n_lines > 0 ? lut_interp(lut_view(K.line[0]), radvel) : 0.0;
+#pragma unroll
+                for (int l = 1; l < 4; l++)
+                    if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
+                weight = nxc_div_const(frac[p] * gg, 1e6, rs_1e6);
+                if (!(__builtin_fabs(weight) <= 1.7976931348623157e308)) my_nonfinite++;
+                have_w = true;
+            }
+            const double ds = dist * K.sin_dphi;
+            const double apix = (3.141592653589793 * (ds * ds)) * K.unit_cm2;   // :194-195
+            double wtemp = nxc_div(weight, apix);
+            const double hx = xs + bx * q, hy = ys + by * q, hz = zs + bz * q;   // :202-206
+            const bool lit = ((hx * hx + hz * hz) > 0x1.0000000000001p+0) || (hy < 0.0);
+            wtemp = lit ? wtemp : wtemp * 0.0;
+            const int64_t i = s0 + j;
+            if (wtemp != 0.0) unsafeAtomicAdd(&radiance[i], wtemp);
+            atomicAdd(&npackets[i], 1ull);
+            my_pairs++;
+            if (included) included[index ? index[p] : p] = 1;
+            if (used_pairs && wtemp > 0.0) {
+                const unsigned long long slot = atomicAdd(n_used, 1ull);
+                if ((long long)slot < used_cap) {
+                    used_pairs[slot] = i;
+                    used_pairs[used_cap + slot] = p;
+                }
+            }
+        }
+    }
+    flush_counter(&ctr->samples_binned, my_pairs);
+    flush_counter(&ctr->nonfinite, my_nonfinite);
+}

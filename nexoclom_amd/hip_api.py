@@ -22,7 +22,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_image_download', 'nxc_counters_get', 'nxc_last_kernel_ms', 'nxc_integrate_const',
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
-           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch')
+           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate')
 
 
 class HipError(RuntimeError):
@@ -42,6 +42,14 @@ class nxc_image_desc(C.Structure):
                 ('reserved', C.c_int32), ('nx', C.c_int64), ('nz', C.c_int64),
                 ('xedges', _dp), ('zedges', _dp), ('line_n', C.c_int64*NXC_MAX_LINES),
                 ('line_v', _dp*NXC_MAX_LINES), ('line_g', _dp*NXC_MAX_LINES)]
+
+
+class nxc_los_desc(C.Structure):
+    _fields_ = [('dphi', C.c_double), ('sin_dphi', C.c_double), ('sin_2dphi', C.c_double),
+                ('cos_threshold', C.c_double), ('vrplanet', C.c_double), ('unit_cm', C.c_double),
+                ('n_lines', C.c_int32), ('reserved', C.c_int32),
+                ('line_n', C.c_int64*NXC_MAX_LINES), ('line_v', _dp*NXC_MAX_LINES),
+                ('line_g', _dp*NXC_MAX_LINES), ('n_ladder', C.c_int64), ('ladder', _dp)]
 
 
 class nxc_counters(C.Structure):
@@ -264,6 +272,45 @@ class Context:
         x, y, z, vy, frac = map(_f64, (x, y, z, vy, frac))
         self._check(self.lib.nxc_image_accumulate(self._h, C.c_int64(len(x)), _p(x), _p(y), _p(z),
                                                   _p(vy), _p(frac)))
+
+    # -- f-1: spacecraft lines of sight ------------------------------------------------------
+    def los_accumulate(self, dphi, sin_dphi, sin_2dphi, cos_threshold, vrplanet, unit_cm, g_tables,
+                       ladder, sc, x, y, z, vy, frac, index=None, n_index=0, used_cap=0):
+        """sc: (8, S) array x,y,z,xbore,ybore,zbore,dist_from_plan,ladder_len.  Returns
+        dict(radiance, npackets, included|None, used (2, m)|None, n_used)."""
+        d = nxc_los_desc()
+        d.dphi, d.sin_dphi, d.sin_2dphi, d.cos_threshold = dphi, sin_dphi, sin_2dphi, cos_threshold
+        d.vrplanet, d.unit_cm = float(vrplanet), float(unit_cm)
+        keep = []
+        d.n_lines = len(g_tables)
+        for k, (v, g) in enumerate(g_tables):
+            v, g = _f64(v), _f64(g)
+            keep += [v, g]
+            d.line_n[k], d.line_v[k], d.line_g[k] = len(v), _p(v), _p(g)
+        lad = _f64(ladder)
+        d.n_ladder, d.ladder = len(lad), _p(lad)
+        sc = _f64(sc)
+        S = sc.shape[1]
+        x, y, z, vy, frac = map(_f64, (x, y, z, vy, frac))
+        P = len(x)
+        radiance = np.zeros(S)
+        npackets = np.zeros(S, dtype=np.int64)
+        idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
+        included = np.zeros(n_index, dtype=np.uint8) if n_index else None
+        used = np.zeros((2, used_cap), dtype=np.int64) if used_cap else None
+        n_used = C.c_int64(0)
+        i64p = C.POINTER(C.c_int64)
+        self._check(self.lib.nxc_los_accumulate(
+            self._h, C.byref(d), C.c_int64(S), _p(sc), C.c_int64(P), _p(x), _p(y), _p(z), _p(vy),
+            _p(frac), idx.ctypes.data_as(i64p) if idx is not None else None, C.c_int64(n_index),
+            _p(radiance), npackets.ctypes.data_as(i64p),
+            included.ctypes.data_as(C.POINTER(C.c_uint8)) if included is not None else None,
+            C.c_int64(used_cap), used.ctypes.data_as(i64p) if used is not None else None,
+            C.byref(n_used)))
+        m = min(int(n_used.value), used_cap)
+        return dict(radiance=radiance, npackets=npackets,
+                    included=None if included is None else included.astype(bool),
+                    used=None if used is None else used[:, :m], n_used=int(n_used.value))
 
     # -- RCCL -------------------------------------------------------------------------------
     def comm_unique_id(self):

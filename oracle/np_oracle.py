@@ -337,3 +337,89 @@ def samples_from_results(results, compress=True, downcast=False):
             v = v.astype(np.float32).astype(np.float64)
         out[name] = v
     return out
+
+
+# --- spacecraft line-of-sight cones ---------------------------------
+
+def los_geometry(sc, outeredge, dphi):
+    """Per-spectrum quantities compute_iteration derives before its loop
+    (data_simulation/compute_iteration.py:105-115,158-167): distance at which the line of sight is
+    cut by the planet (1e30 if it misses) and the geometric ladder of sample distances t_k."""
+    x, y, z = (np.asarray(sc[k], dtype=float) for k in ('x', 'y', 'z'))
+    xb, yb, zb = (np.asarray(sc[k], dtype=float) for k in ('xbore', 'ybore', 'zbore'))
+    dist_from_plan = np.sqrt(x**2 + y**2 + z**2)
+    with np.errstate(invalid='ignore'):
+        ang = np.arccos((-x*xb - y*yb - z*zb) / dist_from_plan)
+        asize_plan = np.arcsin(1. / dist_from_plan)
+    dist_from_plan = dist_from_plan.copy()
+    dist_from_plan[ang > asize_plan] = 1e30
+    ladders = []
+    for i in range(len(x)):
+        x_sc = np.array([x[i], y[i], z[i]])
+        bore = np.array([xb[i], yb[i], zb[i]])
+        b = 2*np.sum(x_sc*bore)
+        c = np.linalg.norm(x_sc)**2 - outeredge**2
+        with np.errstate(invalid='ignore'):
+            dd = (-b + np.sqrt(b**2 - 4*1*c))/2
+        t = [np.sin(dphi)]
+        while t[-1] < dd:
+            t.append(t[-1] + t[-1] * np.sin(dphi))
+        ladders.append(np.array(t))
+    return dist_from_plan, ladders
+
+
+def los_iteration(samples, sc, dphi, outeredge, vrplanet, g_tables, unit_cm, n_index=None):
+    """Radiance and packet count along each spacecraft line of sight for one set of stored samples.
+
+    data_simulation/compute_iteration.py:98-232 (KDTree ball pre-selection :138,171-173; cone and
+    planet cut-off :176-185; weights ModelResult.py:140-170 with out_of_shadow = 1; Apix
+    :194-195; shadow at the LOS foot point :202-206; sum :208).  samples: dict x,y,z,vy,frac
+    [,Index]; sc: dict x,y,z,xbore,ybore,zbore (planet radii, model frame).  Returns radiance (S,),
+    npackets (S,), included (n_index,) bool, used: list of arrays of sample rows with weight > 0.
+    """
+    from sklearn.neighbors import KDTree
+    pts = np.stack([samples['x'], samples['y'], samples['z']], axis=1).astype(float)
+    frac = np.asarray(samples['frac'], dtype=float)
+    radvel_sun = np.asarray(samples['vy'], dtype=float) + vrplanet
+    index = np.asarray(samples.get('Index', np.arange(len(frac))))
+    n_index = int(index.max()) + 1 if n_index is None else n_index
+    dist_from_plan, ladders = los_geometry(sc, outeredge, dphi)
+    S = len(dist_from_plan)
+    tree = KDTree(pts)
+    rad = np.zeros(S)
+    npack = np.zeros(S, dtype=np.int64)
+    included = np.zeros(n_index, dtype=bool)
+    used = [np.zeros(0, dtype=np.int64) for _ in range(S)]
+    for i in range(S):
+        x_sc = np.array([sc['x'][i], sc['y'][i], sc['z'][i]], dtype=float)
+        bore = np.array([sc['xbore'][i], sc['ybore'][i], sc['zbore'][i]], dtype=float)
+        t = ladders[i]
+        Xbore = x_sc[np.newaxis, :] + bore[np.newaxis, :] * t[:, np.newaxis]
+        wid = t * np.sin(dphi*2)
+        ind = np.concatenate(tree.query_radius(Xbore, wid))
+        ilocs = np.unique(ind).astype(int)
+        sub = pts[ilocs]
+        rel = sub - x_sc[np.newaxis, :]
+        dist_sc = np.linalg.norm(rel, axis=1)
+        losrad = np.sum(rel * bore[np.newaxis, :], axis=1)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            cosang = np.sum(rel * bore[np.newaxis, :], axis=1)/dist_sc
+        cosang[cosang > 1] = 1
+        ang = np.arccos(cosang)
+        inview = (losrad < dist_from_plan[i]) & (ang <= dphi)
+        if np.any(inview):
+            rows = ilocs[inview]
+            d = dist_sc[inview]
+            lr = losrad[inview]
+            included[index[rows]] = True
+            weight = packet_weights(frac[rows], radvel_sun[rows], 1., 'radiance', g_tables)
+            Apix = np.pi * (d * np.sin(dphi))**2 * unit_cm**2
+            wtemp = weight / Apix
+            hit = x_sc[np.newaxis, :] + bore[np.newaxis, :] * lr[:, np.newaxis]
+            rhohit = np.linalg.norm(hit[:, [0, 2]], axis=1)
+            out_of_shadow = (rhohit > 1) | (hit[:, 1] < 0)
+            wtemp = wtemp * out_of_shadow
+            rad[i] = wtemp.sum()
+            npack[i] = np.sum(inview)
+            used[i] = rows[wtemp > 0]
+    return rad, npack, included, used

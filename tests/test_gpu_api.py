@@ -117,3 +117,73 @@ def test_modelimage_two_stage_equals_streaming_equals_oracle(ctx, quantity):
     np.testing.assert_allclose(two_stage.image, image*two_stage.atoms_per_packet, rtol=1e-11)
     assert np.allclose(two_stage.xaxis, ex[:-1] + (ex[1]-ex[0])/2)
     assert two_stage.atoms_per_packet == 1e23/(3000*401/12000.)
+
+
+def _orbit(nspec, seed=0):
+    """Synthetic spacecraft geometry: positions on an eccentric polar orbit (1.1 .. 3 R), looking
+    in assorted directions (some at the planet, some at the limb, some away)."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0, 2*np.pi, nspec, endpoint=False)
+    r = 1.6 + 1.3*np.cos(th)**2
+    pos = np.stack([0.3*r*np.cos(th), r*np.sin(th)*0.6 - 0.4, r*np.sin(th)*0.8], 1)
+    look = rng.normal(size=(nspec, 3))
+    look[::3] = -pos[::3] + 0.9*rng.normal(size=(len(pos[::3]), 3))       # roughly planetward
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    return pos, look
+
+
+def test_los_cones_match_oracle(ctx):
+    """f-1: LOSResult through the GPU against the NumPy + KDTree restatement of
+    compute_iteration.py: identical packet counts and `included` flags, radiance to 1e-10."""
+    from nexoclom_amd import LOSResult, SpacecraftData
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    inputs.options.endtime = type(inputs.options.endtime)(9000., 's')
+    inputs.run(4000, packs_per_it=2000, seed=21, context=ctx)
+    pos, look = _orbit(150)
+    sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
+    dphi = np.radians(3.0)
+    los = LOSResult(sc, inputs, {'quantity': 'radiance'}, dphi=dphi, context=ctx)
+    los.simulate_data_from_inputs(sc)
+    scd = {k: sc.data[k].values for k in sc.data.columns}
+    rad = np.zeros(150); npk = np.zeros(150, dtype=np.int64)
+    for out, it in zip(inputs._catalogue, los.iterations):
+        X = Output.restore(out).X
+        smp = dict(x=X.x.values, y=X.y.values, z=X.z.values, vy=X.vy.values, frac=X.frac.values,
+                   Index=X.Index.values)
+        r, n, inc, used = O.los_iteration(smp, scd, dphi, inputs.options.outeredge,
+                                          float(out.vrplanet)/out.unit_km,
+                                          los.g_tables(float(out.aplanet)), out.unit_km*1e5,
+                                          n_index=2000)
+        assert np.array_equal(it['npackets'].values, n)
+        assert np.array_equal(it['included'], inc)
+        np.testing.assert_allclose(it['radiance'].values, r, rtol=1e-10, atol=0)
+        rad += r; npk += n
+    assert npk.sum() > 2000 and (npk > 0).sum() > 50
+    assert np.array_equal(los.npackets_los.values, npk)
+    np.testing.assert_allclose(los.radiance.values, rad*los.atoms_per_packet/1e3, rtol=1e-10)
+
+
+def test_los_used_pairs_and_tiles(ctx):
+    """More spectra than one LDS tile (128), small cone, and the (spectrum, sample) pair list."""
+    from nexoclom_amd import LOSResult, SpacecraftData
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    inputs.options.endtime = type(inputs.options.endtime)(6000., 's')
+    inputs.run(3000, seed=5, context=ctx)
+    pos, look = _orbit(300, seed=3)
+    sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
+    dphi = np.radians(1.0)
+    los = LOSResult(sc, inputs, dphi=dphi, context=ctx)
+    out = inputs._catalogue[0]
+    it = los.compute_iteration(out, sc, used_cap=200000)
+    X = Output.restore(out).X
+    smp = dict(x=X.x.values, y=X.y.values, z=X.z.values, vy=X.vy.values, frac=X.frac.values,
+               Index=X.Index.values)
+    scd = {k: sc.data[k].values for k in sc.data.columns}
+    r, n, inc, used = O.los_iteration(smp, scd, dphi, 25., float(out.vrplanet)/out.unit_km,
+                                      los.g_tables(float(out.aplanet)), out.unit_km*1e5,
+                                      n_index=3000)
+    assert np.array_equal(it['npackets'].values, n)
+    np.testing.assert_allclose(it['radiance'].values, r, rtol=1e-10, atol=0)
+    pairs = set(zip(it['used'][0].tolist(), it['used'][1].tolist()))
+    ref_pairs = {(i, int(row)) for i, rows in enumerate(used) for row in rows}
+    assert it['n_used'] == len(ref_pairs) and pairs == ref_pairs
