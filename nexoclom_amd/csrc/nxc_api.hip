@@ -133,6 +133,18 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
     return NXC_OK;
 }
 
+// Largest double x with sqrt(x) <= e (host sqrt is correctly rounded): r2 > x <=> sqrt(r2) > e,
+// the constant driver's escape test (Output.py:395,410) without a device square root.
+double sqrt_threshold(double e)
+{
+    if (!(e > 0) || !std::isfinite(e)) return e;
+    double x = e * e;
+    if (!std::isfinite(x)) return HUGE_VAL;
+    while (std::sqrt(x) > e) x = std::nextafter(x, 0.0);
+    while (std::sqrt(std::nextafter(x, HUGE_VAL)) <= e) x = std::nextafter(x, HUGE_VAL);
+    return x;
+}
+
 // h*a[n+1][i] for a launch-uniform step: the products NumPy forms per packet (rk5.py:33).
 StepW make_stepw(double h)
 {
@@ -314,8 +326,9 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<true>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
                            h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter, outeredge,
-                           d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter,
+                           sqrt_threshold(outeredge), d_final, d_steps, h->d_image, h->d_counts,
+                           h->d_ctr);
     } else {
         if ((rc = prep_kernel(k_const_fused<false>, lds))) return rc;
         if ((rc = persistent_grid(h, k_const_fused<false>, BLOCK_PERSIST, lds, h->n_packets,
@@ -324,8 +337,8 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL(k_const_fused<false>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
                            h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter, outeredge,
-                           d_final, d_steps, (double *)nullptr,
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter,
+                           sqrt_threshold(outeredge), d_final, d_steps, (double *)nullptr,
                            (unsigned long long *)nullptr, h->d_ctr);
     }
     HIPCHK(hipGetLastError());
@@ -726,14 +739,16 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
                 if (!rc)
                     hipLaunchKernelGGL(k_const_traj<true>, dim3(grid), dim3(NXC_BLOCK), lds,
                                        h->stream, h->F, h->d_blob,
-                                       (int64_t)lds, n, h->d_packets, n_iter, outeredge, d_traj,
+                                       (int64_t)lds, n, h->d_packets, n_iter, sqrt_threshold(outeredge),
+                                       d_traj,
                                        nrec, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
             } else {
                 rc = prep_kernel(k_const_traj<false>, lds);
                 if (!rc)
                     hipLaunchKernelGGL(k_const_traj<false>, dim3(grid), dim3(NXC_BLOCK), lds,
                                        h->stream, h->F, h->d_blob,
-                                       (int64_t)lds, n, h->d_packets, n_iter, outeredge, d_traj,
+                                       (int64_t)lds, n, h->d_packets, n_iter, sqrt_threshold(outeredge),
+                                       d_traj,
                                        nrec, d_final, d_steps, (double *)nullptr,
                                        (unsigned long long *)nullptr, h->d_ctr);
             }

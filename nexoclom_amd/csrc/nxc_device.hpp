@@ -74,12 +74,14 @@ NXC_DEV LutView lut_view(const LutDesc &d)
     return v;
 }
 
+// A NaN abscissa is clamped like any other value (np.interp would return NaN): callers that must
+// notice it test their argument themselves; in the integrator a NaN velocity has already made
+// the position NaN.
 NXC_DEV double lut_interp(const LutView &t, double xin)
 {
     // Clamping to [x0, xlast] reproduces np.interp's end values exactly: at x0 record 0 gives
     // slope*0 + fp[0]; the last record has slope 0.
-    double x = xin < t.x0 ? t.x0 : xin;
-    x = x > t.xlast ? t.xlast : x;
+    const double x = __builtin_fmin(__builtin_fmax(xin, t.x0), t.xlast);
     int c = (int)((x - t.x0) * t.inv_w);
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
@@ -98,8 +100,7 @@ NXC_DEV double lut_interp(const LutView &t, double xin)
         const LutRec rw = lds_rec(t.rec + 32 * j);
         r.xp = rw.xp; r.fp = rw.fp; r.sl = rw.sl;
     }
-    const double v = r.sl * (x - r.xp) + r.fp;
-    return xin != xin ? xin : v;
+    return r.sl * (x - r.xp) + r.fp;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,28 +127,35 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
 {
     double gx = 0.0, gy = 0.0, gz = 0.0;
     if (F.grav) {                                         // state.py:19-21
-        const double r3 = nxc_cube(nxc_sqrt((x * x + y * y) + z * z));
+        const double s2 = (x * x + y * y) + z * z;
         const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
-        if (nxc_mid_range(r3)) {                          // one refined reciprocal, three quotients
+        if (s2 > 0x1p-130 && s2 < 0x1p+130) {
+            // r in 2^+-65, r^3 in 2^+-195: the un-wrapped sqrt / division chains are exact here;
+            // one refined reciprocal serves the three quotients
+            const double r3 = nxc_cube(nxc_sqrt_mid(s2));
             const double rinv = nxc_recip_seed(r3);
             gx = nxc_div_seeded(nx, r3, rinv);
             gy = nxc_div_seeded(ny, r3, rinv);
             gz = nxc_div_seeded(nz, r3, rinv);
         } else {
+            const double r3 = nxc_cube(__builtin_sqrt(s2));
             gx = nx / r3; gy = ny / r3; gz = nz / r3;
         }
     }
     const bool lit = sunlit(x, y, z);
     double ry = 0.0;
     if (F.rad) {                                          // state.py:27-36
-        double vv = vy + F.vrplanet;
-        ry = lut_interp(T, vv) * (lit ? 1.0 : 0.0);
+        const double vv = vy + F.vrplanet;
+        // interp * out_of_shadow: the product with False is a zero whose sign cannot matter in
+        // gy + ry
+        const double a = lut_interp(T, vv);
+        ry = lit ? a : 0.0;
     }
     ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
     ay = gy + ry;
     az = gz;
     if (F.loss == LOSS_LIFETIME) ion = F.inv_lifetime;    // state.py:44-46
-    else if (F.loss == LOSS_PHOTO) ion = F.photo * (lit ? 1.0 : 0.0);   // state.py:48-52
+    else if (F.loss == LOSS_PHOTO) ion = lit ? F.photo : 0.0;   // state.py:48-52 (photo * bool)
     else ion = 0.0;
 }
 
@@ -242,13 +250,14 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
 // Post-step tests with stickcoef == 1.  Constant driver: Output.py:395-416 (r = |x|); variable
 // driver: Output.py:308-324, which compares r^2 with 1 AND with outeredge (reference quirk).
 // (sqrt(r2) - 1) < 0  <=>  r2 < 1 for a correctly rounded sqrt.
-template <bool R_SQUARED>
-NXC_DEV void apply_fate(double (&s)[8], double outeredge)
+// `edge2` is the host-computed threshold on r^2: for the constant driver the largest double whose
+// correctly rounded square root is <= outeredge (so r2 > edge2  <=>  sqrt(r2) > outeredge), for
+// the variable driver outeredge itself.
+NXC_DEV void apply_fate(double (&s)[8], double edge2)
 {
-    double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
-    double rr = R_SQUARED ? r2 : nxc_sqrt(r2);
+    const double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
     if (r2 < 1.0) s[7] = 0.0;
-    if (rr > outeredge) s[7] = 0.0;
+    if (r2 > edge2) s[7] = 0.0;
     if (s[7] < 1e-10) s[7] = 0.0;
     if (s[7] == 0.0) s[0] = 0.0;
 }
@@ -369,7 +378,7 @@ NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y
         w = nxc_div_const(lit * gg, 1e6, R.rs_1e6);
     }
     w = nxc_div_const(w, R.apix, R.rs_apix);                       // ModelImage.py:262
-    if (!(__builtin_fabs(w) <= 1.7976931348623157e308)) nonfinite++;   // ModelResult.py:170
+    if (!(__builtin_fabs(w) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;   // :170
     const int64_t pix = (int64_t)ix * R.nz + iz;
     if (R.dbg == 1) return 1;
     if (w != 0.0 && R.dbg != 3) unsafeAtomicAdd(&image[pix], w);

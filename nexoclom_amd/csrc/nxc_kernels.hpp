@@ -108,7 +108,7 @@ template <bool IMAGE>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
              int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t n_iter,
-             double outeredge, double *__restrict__ traj, int64_t nrec,
+             double edge2, double *__restrict__ traj, int64_t nrec,
              double *__restrict__ final_out, long long *__restrict__ steps_out,
              double *__restrict__ image, unsigned long long *__restrict__ counts,
              DevCounters *__restrict__ ctr)
@@ -134,7 +134,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         long long k = 0;
         while (alive && k < n_iter) {
             rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-            apply_fate<false>(s, outeredge);
+            apply_fate(s, edge2);
             k++; my_steps++;
             if (k < nrec) {
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
               const unsigned *__restrict__ order, int64_t n_iter,
-              double outeredge, double *__restrict__ final_out,
+              double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ image,
               unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr)
 {
@@ -261,7 +261,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             bool done = !(s[7] > 0.0) || k >= n_iter;
             if (!done) {
                 rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-                apply_fate<false>(s, outeredge);
+                apply_fate(s, edge2);
                 k++; my_steps++;
                 if (s[7] > 0.0) {
                     if (IMAGE) {
@@ -349,7 +349,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                         double hold = h;
                         if (e < 1e-7) { e = 1.0; hold = h * 10; }
                         if (e < 1.0) {
-                            apply_fate<true>(t, outeredge);
+                            apply_fate(t, outeredge);
 #pragma unroll
                             for (int c = 0; c < 8; c++) s[c] = t[c];
                         } else {
@@ -492,7 +492,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                 for (int l = 1; l < 4; l++)
                     if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
                 weight = nxc_div_const(frac[p] * gg, 1e6, rs_1e6);
-                if (!(__builtin_fabs(weight) <= 1.7976931348623157e308)) my_nonfinite++;
+                if (!(__builtin_fabs(weight) <= 1.7976931348623157e308) || radvel != radvel) my_nonfinite++;
                 have_w = true;
             }
             const double ds = dist * K.sin_dphi;

@@ -33,6 +33,21 @@ NXC_DEV bool nxc_mid_range(double a)
     return (m > 0x1p-200) && (m < 0x1p+200);
 }
 
+// sqrt for an argument already known to lie in the middle exponent range
+NXC_DEV double nxc_sqrt_mid(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d0 = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, x);
+    return __builtin_fma(d1, h, g);
+}
+
 NXC_DEV double nxc_sqrt(double x)
 {
     if (!nxc_mid_range(x)) return __builtin_sqrt(x);
@@ -65,6 +80,9 @@ NXC_DEV double nxc_div_seeded(double n, double d, double y)
     const double r = __builtin_fma(-d, q, n);
     return __builtin_fma(r, y, q);
 }
+
+// n/d for operands known to be mid-range (n may also be exactly 0)
+NXC_DEV double nxc_div_mid(double n, double d) { return nxc_div_seeded(n, d, nxc_recip_seed(d)); }
 
 NXC_DEV double nxc_div(double n, double d)
 {
@@ -107,8 +125,9 @@ NXC_DEV double nxc_exp(double x)
     }
     double t = x * x;
     double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    if (k == 0) return 1.0 - (nxc_div(x * c, c - 2.0) - x);
-    double y = 1.0 - ((lo - nxc_div(x * c, 2.0 - c)) - hi);
+    // |x| >= 2^-28 here and c = x(1 - ...) so both quotients have mid-range operands
+    if (k == 0) return 1.0 - (nxc_div_mid(x * c, c - 2.0) - x);
+    double y = 1.0 - ((lo - nxc_div_mid(x * c, 2.0 - c)) - hi);
     if (k >= -1021)
         return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
     return __longlong_as_double(__double_as_longlong(y) + ((long long)(k + 1000) << 52))
@@ -142,7 +161,7 @@ NXC_DEV double nxc_log(double x)
         double R = f * f * (0.5 - 0.33333333333333333 * f);
         return k == 0 ? f - R : dk * LN2_HI - ((R - dk * LN2_LO) - f);
     }
-    double s = nxc_div(f, 2.0 + f), z = s * s, w = z * z;
+    double s = nxc_div_mid(f, 2.0 + f), z = s * s, w = z * z;     // |f| >= 2^-20 here
     double t1 = w * (L2 + w * (L4 + w * L6));
     double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
     double R = t2 + t1;
