@@ -212,6 +212,7 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
         }
 #pragma unroll
         for (int i = 1; i <= n; i++) {
+            if (Tableau::A[n + 1][i] == 0.0) continue;   // b5[1] = 0: the term is a zero
             const double w = UNIFORM_H ? W.w[n * (n + 1) / 2 + i] : h * Tableau::A[n + 1][i];
             nx += w * kv[i][0];
             ny += w * kv[i][1];
