@@ -100,17 +100,18 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
     const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 31) & ~size_t(31);
     out.bytes.assign((size_t)n * 32 + cell_bytes, 0);
     double *rec = reinterpret_cast<double *>(out.bytes.data());
+    double *fs = rec + 2 * n;     // {fp, slope} pairs after the {xp, xp_next} pairs
     for (int64_t j = 0; j < n; j++) {
-        rec[4 * j + 0] = xp[j];
-        rec[4 * j + 1] = fp[j];
+        rec[2 * j + 0] = xp[j];
+        fs[2 * j + 0] = fp[j];
         if (j + 1 < n) {      // np.interp's slope, the same IEEE quotient
-            rec[4 * j + 2] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-            rec[4 * j + 3] = xp[j + 1];
+            fs[2 * j + 1] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+            rec[2 * j + 1] = xp[j + 1];
         } else {
-            rec[4 * j + 2] = 0.0;
-            rec[4 * j + 3] = HUGE_VAL;
+            fs[2 * j + 1] = 0.0;
+            rec[2 * j + 1] = HUGE_VAL;
         }
-        if (!std::isfinite(rec[4 * j + 1]) || !std::isfinite(rec[4 * j + 2]))
+        if (!std::isfinite(fs[2 * j]) || !std::isfinite(fs[2 * j + 1]))
             return fail(NXC_ERR_ARG, std::string(what) + ": table values must be finite");
     }
     unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * n);

@@ -18,8 +18,11 @@
 // node the product is +-0 and the sum is fp[j], np.interp's special case).
 //
 // Global image of one table, staged verbatim into LDS (32-byte aligned):
-//   n records {xp[j], fp[j], slope[j], xp[j+1]}  (last: slope 0, xp[n] = +inf)
+//   n pairs {xp[j], xp[j+1]}            (last: xp[n] = +inf)
+//   n pairs {fp[j], slope[j]}           (last: slope 0)
 //   then (ncell+1) uint16 cell->index entries, padded to a multiple of 32 bytes.
+// (Two 16-byte-stride arrays rather than one 32-byte record: a ds_read_b128 of random rows then
+// spreads over 16 bank quads instead of 8, which halves the LDS bank conflicts.)
 // cell[c] = the largest j with xp[j] <= left edge of uniform cell c.  A lookup is two dependent
 // LDS round trips: the cell entry, then records j and j+1 (four ds_read_b128); the record whose
 // [xp, xp_next) holds x is selected.  Cells are fine enough (ncell >= 4n) that this almost always
@@ -51,15 +54,13 @@ NXC_DEV int lds_u16(int byte_off)
 
 struct LutRec { double xp, fp, sl, xn; };
 
-NXC_DEV LutRec lds_rec(int byte_off)
+NXC_DEV double2 lds_f64x2(int byte_off)
 {
-    const double2 *p = reinterpret_cast<const double2 *>(nxc_lds + byte_off);
-    const double2 a = p[0], b = p[1];
-    return LutRec{a.x, a.y, b.x, b.y};
+    return *reinterpret_cast<const double2 *>(nxc_lds + byte_off);
 }
 
 struct LutView {          // byte offsets into the LDS block
-    int rec, cell;
+    int rec, fs, cell;    // {xp, xp_next} pairs, {fp, slope} pairs, cell index
     int n, ncell;
     double x0, xlast, f_first, f_last, inv_w;
 };
@@ -68,6 +69,7 @@ NXC_DEV LutView lut_view(const LutDesc &d)
 {
     LutView v;
     v.rec = (int)d.offset_bytes;
+    v.fs = v.rec + 16 * d.n;
     v.cell = v.rec + 32 * d.n;
     v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast;
     v.f_first = d.f_first; v.f_last = d.f_last; v.inv_w = d.inv_w;
@@ -86,19 +88,19 @@ NXC_DEV double lut_interp(const LutView &t, double xin)
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
     const int j1 = j + 1 < t.n ? j + 1 : t.n - 1;
-    const LutRec r0 = lds_rec(t.rec + 32 * j);
-    const LutRec r1 = lds_rec(t.rec + 32 * j1);
-    const bool in0 = (x >= r0.xp) && (x < r0.xn);
-    const bool in1 = (x >= r1.xp) && (x < r1.xn);
+    const double2 a0 = lds_f64x2(t.rec + 16 * j), a1 = lds_f64x2(t.rec + 16 * j1);
+    const double2 b0 = lds_f64x2(t.fs + 16 * j), b1 = lds_f64x2(t.fs + 16 * j1);
+    const bool in0 = (x >= a0.x) && (x < a0.y);
+    const bool in1 = (x >= a1.x) && (x < a1.y);
     LutRec r;
-    r.xp = in0 ? r0.xp : r1.xp;
-    r.fp = in0 ? r0.fp : r1.fp;
-    r.sl = in0 ? r0.sl : r1.sl;
+    r.xp = in0 ? a0.x : a1.x;
+    r.fp = in0 ? b0.x : b1.x;
+    r.sl = in0 ? b0.y : b1.y;
     if (__builtin_expect(!(in0 || in1), 0)) {  // rare: walk to the interval
-        while (j > 0 && x < lds_f64(t.rec + 32 * j)) --j;
-        while (x >= lds_f64(t.rec + 32 * j + 24)) ++j;
-        const LutRec rw = lds_rec(t.rec + 32 * j);
-        r.xp = rw.xp; r.fp = rw.fp; r.sl = rw.sl;
+        while (j > 0 && x < lds_f64(t.rec + 16 * j)) --j;
+        while (x >= lds_f64(t.rec + 16 * j + 8)) ++j;
+        const double2 aw = lds_f64x2(t.rec + 16 * j), bw = lds_f64x2(t.fs + 16 * j);
+        r.xp = aw.x; r.fp = bw.x; r.sl = bw.y;
     }
     return r.sl * (x - r.xp) + r.fp;
 }
