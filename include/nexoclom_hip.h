@@ -129,6 +129,30 @@ int nxc_image_download(nxc_handle *h, double *image /* nx*nz */, uint64_t *count
 int nxc_counters_get(nxc_handle *h, nxc_counters *out);
 int nxc_last_kernel_ms(nxc_handle *h, float *ms);  /* HIP-event time of the last integrate/image launch */
 
+/* ---- f-4: initial states sampled on the device -----------------------------------------------------
+ * Fills the resident packet set with n packets of the uniform-surface / flat|gaussian-speed /
+ * isotropic|radial source (initial_state/source_distribution.py:47-62,141-171,198-252) using a
+ * counter-based generator (Philox-4x32-10 keyed by seed; counter = first_index + i), so shards on
+ * different GPUs draw disjoint, reproducible packets.  soa_out (nullable) receives the [8][n]
+ * states.  Statistically equivalent to the reference's NumPy sampler, not draw-for-draw. */
+typedef struct nxc_source_desc {
+    double endtime;        /* s                                                                 */
+    double exobase;        /* R                                                                 */
+    double sinlat0, sinlat1; /* sin of the latitude range                                       */
+    double lon0, lon1;     /* rad; lon1 already += 2 pi when the range wraps                    */
+    double vprob, vwidth;  /* km/s: flat = vprob +- vwidth (delv); gaussian = mean, sigma       */
+    double unit_km;        /* planet radius                                                     */
+    double sinalt0, sinalt1, az0, az1;   /* isotropic launch cone                               */
+    int32_t random_time;   /* 1: t = u*endtime (variable-step runs, Output.py:138-139)          */
+    int32_t speed_type;    /* 0 flat, 1 gaussian                                                */
+    int32_t angular_type;  /* 0 radial, 1 isotropic                                             */
+    int32_t is_planet;     /* longitude convention (source_distribution.py:13-28)               */
+    uint64_t seed;
+    int64_t first_index;
+} nxc_source_desc;
+
+int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out);
+
 /* ---- a-3 (+ fused a-6..a-8): constant-step driver over the resident packets --------------------
  * Runs n_iter iterations of {rk5(step); impact r<1; escape r>outeredge; vanish frac<1e-10}
  * (Output.py:384-431) for every packet until it dies.

@@ -122,7 +122,8 @@ class ModelResult:
 
 class ModelImage(ModelResult):
     def __init__(self, inputs, params, overwrite=False, distribute=None, *, npackets=None,
-                 seed=None, packs_per_it=None, downcast=True, device=0, context=None):
+                 seed=None, packs_per_it=None, downcast=True, device=0, context=None,
+                 sampler='numpy'):
         super().__init__(inputs, params)
         self.type = 'image'
         self.origin = self.params.get('origin', inputs.geometry.planet)
@@ -160,7 +161,7 @@ class ModelImage(ModelResult):
         self.counters = {}
 
         if npackets is not None:
-            self._stream(int(npackets), seed, packs_per_it, downcast)
+            self._stream(int(npackets), seed, packs_per_it, downcast, sampler)
         else:
             outputs = [o for o in inputs._catalogue]
             if not outputs:
@@ -221,7 +222,7 @@ class ModelImage(ModelResult):
         return (Histogram2dResult(image, self.xedges, self.zedges),
                 Histogram2dResult(counts.astype(float), self.xedges, self.zedges))
 
-    def _stream(self, npackets, seed, packs_per_it, downcast):
+    def _stream(self, npackets, seed, packs_per_it, downcast, sampler='numpy'):
         """Fused integrate + image over ``npackets`` packets, chunked like Input.run."""
         from .Output import Output, n_output_steps
         inputs = self.inputs
@@ -236,13 +237,17 @@ class ModelImage(ModelResult):
         totals = {}
         while done < npackets:
             n = min(chunk, npackets - done)
-            out = Output(inputs, n, seed=None if seed is None else seed + k, integrate=False,
-                         save=False, context=ctx)
+            if sampler == 'device':      # one counter space: chunk k continues at packet `done`
+                out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
+                             sampler='device', first_index=done, materialize_x0=False)
+            else:
+                out = Output(inputs, n, seed=None if seed is None else seed + k,
+                             integrate=False, save=False, context=ctx)
             if first:
                 ctx.set_forces(**out.forces_kwargs())
                 self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
                 first = False
-            ctx.upload_soa(out.x0_soa())
+            out.upload(ctx)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():
                 totals[key] = totals.get(key, 0) + v

@@ -14,7 +14,11 @@ loss_info, randgen, compress, inputs, planet) and the same column order of ``X``
   reference would read.
 * keyword-only extras: ``device`` (GPU index), ``integrate`` (False: set up and sample X0 only),
   ``keep_trajectory`` (False: constant-step runs never materialise the (N, 8, nsteps) tensor --
-  used by the fused integrate+image path), ``context`` (share one hip_api.Context).
+  used by the fused integrate+image path), ``context`` (share one hip_api.Context),
+  ``sampler`` ('numpy': the reference's seeded draw order on the host; 'device': Philox on the
+  GPU, statistically equivalent, for runs where host sampling would dominate),
+  ``first_index`` (offset of this chunk in the device sampler's counter space) and
+  ``materialize_x0`` (False: leave the device-sampled states on the GPU).
 """
 import os
 
@@ -43,7 +47,8 @@ def n_output_steps(endtime, step):
 
 class Output:
     def __init__(self, inputs, npackets, compress=True, run_model=True, seed=None, *,
-                 device=0, integrate=True, keep_trajectory=True, context=None, save=True):
+                 device=0, integrate=True, keep_trajectory=True, context=None, save=True,
+                 sampler='numpy', first_index=0, materialize_x0=True):
         self.inputs = inputs
         self.planet = inputs.geometry.planet
         self._ctx = context
@@ -101,20 +106,33 @@ class Output:
 
             if self.planet.moons is not None:                           # Output.py:153-155
                 assert False, 'Not set up'
-
-            if inputs.spatialdist.type in ('uniform', 'surface map', 'surface spot'):
-                surface_distribution(self)
-            else:
-                assert 0, 'Not a valid spatial distribution type'
-            speed_distribution(self)
-            angular_distribution(self)
-
             if inputs.geometry.planet.object != inputs.geometry.startpoint:
                 assert 0, 'Not set up yet'
 
-            cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac', 'v',
-                    'longitude', 'latitude', 'local_time', 'altitude', 'azimuth']
-            self.X0 = self.X0[cols]
+            self.sampler = sampler
+            self._resident = False
+            if sampler == 'device':
+                soa = self.context().sample_packets(
+                    npackets, 0 if seed is None else seed, first_index,
+                    download=materialize_x0, **self.source_desc())
+                self._resident = True
+                if materialize_x0:
+                    self.X0 = pd.DataFrame({c: soa[k] for k, c in enumerate(STATE_COLS)})
+                    self.X0['v'] = np.sqrt(self.X0.vx**2 + self.X0.vy**2 + self.X0.vz**2)
+                else:
+                    self.X0 = pd.DataFrame()
+            elif sampler == 'numpy':
+                if inputs.spatialdist.type in ('uniform', 'surface map', 'surface spot'):
+                    surface_distribution(self)
+                else:
+                    assert 0, 'Not a valid spatial distribution type'
+                speed_distribution(self)
+                angular_distribution(self)
+                cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac', 'v',
+                        'longitude', 'latitude', 'local_time', 'altitude', 'azimuth']
+                self.X0 = self.X0[cols]
+            else:
+                raise ValueError("sampler must be 'numpy' or 'device'")
             self.nsteps = None
             self.X = pd.DataFrame()
             self.counters = {}
@@ -168,6 +186,40 @@ class Output:
             kw.update(v_tab=self.radpres.velocity, a_tab=self.radpres.accel)
         return kw
 
+    def source_desc(self):
+        """Fields of nxc_source_desc for these inputs (the sources the device sampler covers:
+        uniform surface; flat or gaussian speed; isotropic or radial direction)."""
+        sd, vd, ad = self.inputs.spatialdist, self.inputs.speeddist, self.inputs.angulardist
+        if sd.type != 'uniform' or vd.type not in ('flat', 'gaussian') \
+                or ad.type not in ('isotropic', 'radial'):
+            raise NotImplementedError("sampler='device' supports uniform / flat|gaussian / "
+                                      "isotropic|radial sources")
+        lon0, lon1 = (float(v) for v in sd.longitude)
+        if lon0 > lon1:
+            lon1 += 2*np.pi
+        d = dict(endtime=self.inputs.options.endtime.value, exobase=float(sd.exobase),
+                 sinlat0=float(np.sin(sd.latitude[0])), sinlat1=float(np.sin(sd.latitude[1])),
+                 lon0=lon0, lon1=lon1, vprob=vd.vprob.value,
+                 vwidth=(vd.delv.value if vd.type == 'flat' else vd.sigma.value),
+                 unit_km=self.unit_km, random_time=int(self.inputs.options.step_size == 0),
+                 speed_type=0 if vd.type == 'flat' else 1,
+                 angular_type=0 if ad.type == 'radial' else 1,
+                 is_planet=int(self.planet.type == 'Planet'),
+                 sinalt0=0.0, sinalt1=1.0, az0=0.0, az1=2*np.pi)
+        if ad.type == 'isotropic':
+            az0, az1 = (float(v) for v in ad.azimuth)
+            if az0 > az1:
+                az0, az1 = az1, az0 + 2*np.pi
+            d.update(sinalt0=float(np.sin(ad.altitude[0])), sinalt1=float(np.sin(ad.altitude[1])),
+                     az0=az0, az1=az1)
+        return d
+
+    def upload(self, ctx):
+        """Make this Output's initial states the context's resident packet set."""
+        if getattr(self, '_resident', False) and ctx is self._ctx:
+            return
+        ctx.upload_soa(self.x0_soa())
+
     def x0_soa(self):
         """Initial state as the (8, N) struct-of-arrays block the C ABI takes."""
         return np.ascontiguousarray(self.X0[STATE_COLS].values.T, dtype=np.float64)
@@ -189,7 +241,7 @@ class Output:
         self.nsteps, n_iter = n_output_steps(endtime, step)
         ctx = self.context()
         ctx.set_forces(**self.forces_kwargs())
-        ctx.upload_soa(self.x0_soa())
+        self.upload(ctx)
         n = self.npackets
         if keep_trajectory:
             res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)

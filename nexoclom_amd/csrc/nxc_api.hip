@@ -678,6 +678,69 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     return NXC_OK;
 }
 
+// Device-side queue order (the same counting sort nxc_packets_upload does on the host).
+static int order_on_device(nxc_handle *h, double k2max)
+{
+    const int64_t n = h->n_packets;
+    h->have_order = false;
+    if (n < 2 || n >= (int64_t)0xffffffffll || !(k2max > 0) || !std::isfinite(k2max)) return NXC_OK;
+    int rc = ensure(reinterpret_cast<void **>(&h->d_order), &h->order_cap, (size_t)n * sizeof(unsigned));
+    if (rc) return rc;
+    const size_t hb = (size_t)NXC_ORDER_BINS * sizeof(unsigned long long);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap, hb))) return rc;
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(h->d_steps);
+    const double scale = (double)(NXC_ORDER_BINS - 1) / k2max;
+    HIPCHK(hipMemsetAsync(d_hist, 0, hb, h->stream));
+    const int grid = flat_grid(h, n, NXC_BLOCK);
+    hipLaunchKernelGGL(k_order_hist, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
+                       scale, d_hist);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> hist(NXC_ORDER_BINS), start(NXC_ORDER_BINS);
+    HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long acc = 0;
+    for (int b = 0; b < NXC_ORDER_BINS; b++) { start[b] = acc; acc += hist[b]; }
+    if (acc != (unsigned long long)n) return fail(NXC_ERR_HIP, "order histogram lost packets");
+    HIPCHK(hipMemcpyAsync(d_hist, start.data(), hb, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
+                       scale, d_hist, h->d_order);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_order = true;
+    return NXC_OK;
+}
+
+int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out)
+{
+    if (!h || !d || n < 1) return fail(NXC_ERR_ARG, "bad arguments");
+    if (d->speed_type < 0 || d->speed_type > 1 || d->angular_type < 0 || d->angular_type > 1 ||
+        !(d->unit_km > 0) || !(d->exobase > 0))
+        return fail(NXC_ERR_ARG, "bad nxc_source_desc");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)8 * n * sizeof(double);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
+    if (rc) return rc;
+    SourceK K{};
+    K.endtime = d->endtime; K.exobase = d->exobase; K.sinlat0 = d->sinlat0; K.sinlat1 = d->sinlat1;
+    K.lon0 = d->lon0; K.lon1 = d->lon1; K.vprob = d->vprob; K.vwidth = d->vwidth;
+    K.unit_km = d->unit_km; K.sinalt0 = d->sinalt0; K.sinalt1 = d->sinalt1; K.az0 = d->az0;
+    K.az1 = d->az1; K.random_time = d->random_time; K.speed_type = d->speed_type;
+    K.angular_type = d->angular_type; K.is_planet = d->is_planet; K.seed = d->seed;
+    K.first_index = d->first_index;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(k_sample, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0, h->stream, K,
+                       n, h->d_packets);
+    HIPCHK(hipGetLastError());
+    if ((rc = end_timed(h))) return rc;
+    h->n_packets = n;
+    const double vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
+                                            : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
+    if ((rc = order_on_device(h, vmax * vmax))) return rc;
+    if (soa_out) HIPCHK(hipMemcpyAsync(soa_out, h->d_packets, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags)
 {

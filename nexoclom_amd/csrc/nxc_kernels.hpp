@@ -518,3 +518,135 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     flush_counter(&ctr->samples_binned, my_pairs);
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
+
+// ---------------------------------------------------------------------------------------------
+// On-device initial states: the uniform-surface / flat|gaussian speed /
+// isotropic|radial direction source of initial_state/source_distribution.py:47-62,141-171,198-252,
+// one thread per packet, written straight into the resident SoA.  Draws come from a counter-based
+// generator (Philox-4x32-10; counter = packet index, draw block, stream; key = seed) so packet i
+// is the same whatever the launch geometry or the number of GPUs.  The reference's sampler uses
+// NumPy's PCG64 stream, so parity with it is statistical (KS tests); parity with the oracle's
+// NumPy Philox restatement is to rounding of sin/cos/asin/log.
+struct SourceK {
+    double endtime, exobase, sinlat0, sinlat1, lon0, lon1, vprob, vwidth, unit_km;
+    double sinalt0, sinalt1, az0, az1;
+    int random_time, speed_type, angular_type, is_planet;
+    unsigned long long seed;
+    long long first_index;
+};
+
+NXC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                           unsigned k1, unsigned (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two uniform doubles in [0,1): ((a << 32 | b) >> 11) * 2^-53
+NXC_DEV void philox_pair(unsigned long long index, unsigned block, unsigned stream,
+                         unsigned long long seed, double &u0, double &u1)
+{
+    unsigned r[4];
+    philox4x32_10((unsigned)index, (unsigned)(index >> 32), block, stream, (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    u0 = (double)((((unsigned long long)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
+    u1 = (double)((((unsigned long long)r[2] << 32) | r[3]) >> 11) * 0x1p-53;
+}
+
+constexpr unsigned NXC_STREAM_SOURCE = 0x5a0u;
+
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_sample(SourceK K, int64_t n, double *__restrict__ soa)
+{
+    const double TWO_PI = 6.283185307179586;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long gi = (unsigned long long)(K.first_index + i);
+        double ut, ulat, ulon, uspd, ualt, uaz;
+        philox_pair(gi, 0, NXC_STREAM_SOURCE, K.seed, ut, ulat);
+        philox_pair(gi, 1, NXC_STREAM_SOURCE, K.seed, ulon, uspd);
+        philox_pair(gi, 2, NXC_STREAM_SOURCE, K.seed, ualt, uaz);
+        const double time = K.random_time ? ut * K.endtime : K.endtime;       // Output.py:136-139
+        const double sinlat = K.sinlat0 + (K.sinlat1 - K.sinlat0) * ulat;     // :51-53
+        const double lat = asin(sinlat);
+        double lon = fmod(K.lon0 + (K.lon1 - K.lon0) * ulon, TWO_PI);         // :56-62
+        const double clat = cos(lat);
+        const double x0 = (K.is_planet ? 1.0 : -1.0) * K.exobase * sin(lon) * clat;   // :12-28
+        const double y0 = -K.exobase * cos(lon) * clat;
+        const double z0 = K.exobase * sin(lat);
+        double v;
+        if (K.speed_type == 0) {                                               // flat :169-171
+            v = uspd * 2 * K.vwidth + K.vprob - K.vwidth;
+        } else {                                                               // gaussian :141-147
+            double g0, g1;
+            philox_pair(gi, 3, NXC_STREAM_SOURCE, K.seed, g0, g1);
+            const double zn = sqrt(-2.0 * log(1.0 - g0)) * cos(TWO_PI * g1);
+            v = K.vwidth == 0.0 ? K.vprob : zn * K.vwidth + K.vprob;
+        }
+        v = v / K.unit_km;                                                     // :184
+        double alt, az;
+        if (K.angular_type == 0) {                                             // radial :198-201
+            alt = 1.5707963267948966; az = 0.0;
+        } else {                                                               // isotropic :202-212
+            alt = asin(ualt * (K.sinalt1 - K.sinalt0) + K.sinalt0);
+            az = K.az0 + (K.az1 - K.az0) * uaz;
+        }
+        const double v_rad = sin(alt), v_t0 = cos(alt) * cos(az), v_t1 = cos(alt) * sin(az);
+        const double rn = sqrt((x0 * x0 + y0 * y0) + z0 * z0);                 // :236-245
+        const double en = sqrt(y0 * y0 + x0 * x0);
+        const double n0 = -z0 * x0, n1 = -z0 * y0, n2 = x0 * x0 + y0 * y0;
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        const double dx = (v_t0 * (n0 / nn) + v_t1 * (y0 / en)) + v_rad * (x0 / rn);   // :247-248
+        const double dy = (v_t0 * (n1 / nn) + v_t1 * (-x0 / en)) + v_rad * (y0 / rn);
+        const double dz = (v_t0 * (n2 / nn) + v_t1 * 0.0) + v_rad * (z0 / rn);
+        soa[0 * n + i] = time;
+        soa[1 * n + i] = x0; soa[2 * n + i] = y0; soa[3 * n + i] = z0;
+        soa[4 * n + i] = dx * v; soa[5 * n + i] = dy * v; soa[6 * n + i] = dz * v;
+        soa[7 * n + i] = 1.0;
+    }
+}
+
+// Queue order on the device: counting sort of the packet indices by decreasing |v|^2.
+constexpr int NXC_ORDER_BINS = 4096;
+
+NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t n, int64_t i, double scale)
+{
+    const double vx = soa[4 * n + i], vy = soa[5 * n + i], vz = soa[6 * n + i];
+    const double f = (vx * vx + vy * vy + vz * vz) * scale;
+    int b = (f >= 0.0 && f < (double)NXC_ORDER_BINS) ? (int)f : (f >= (double)NXC_ORDER_BINS ? NXC_ORDER_BINS - 1 : 0);
+    return NXC_ORDER_BINS - 1 - b;
+}
+
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_order_hist(const double *__restrict__ soa, int64_t n, double scale,
+             unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned lh[NXC_ORDER_BINS];
+    for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x) lh[b] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&lh[speed_bin(soa, n, i, scale)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
+        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_order_scatter(const double *__restrict__ soa, int64_t n, double scale,
+                unsigned long long *__restrict__ cursor, unsigned *__restrict__ order)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long pos = atomicAdd(&cursor[speed_bin(soa, n, i, scale)], 1ull);
+        order[pos] = (unsigned)i;
+    }
+}

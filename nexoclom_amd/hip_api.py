@@ -22,7 +22,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_image_download', 'nxc_counters_get', 'nxc_last_kernel_ms', 'nxc_integrate_const',
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
-           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate')
+           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample')
 
 
 class HipError(RuntimeError):
@@ -50,6 +50,14 @@ class nxc_los_desc(C.Structure):
                 ('n_lines', C.c_int32), ('reserved', C.c_int32),
                 ('line_n', C.c_int64*NXC_MAX_LINES), ('line_v', _dp*NXC_MAX_LINES),
                 ('line_g', _dp*NXC_MAX_LINES), ('n_ladder', C.c_int64), ('ladder', _dp)]
+
+
+class nxc_source_desc(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ('endtime', 'exobase', 'sinlat0', 'sinlat1', 'lon0', 'lon1', 'vprob', 'vwidth',
+                 'unit_km', 'sinalt0', 'sinalt1', 'az0', 'az1')] + \
+               [(k, C.c_int32) for k in ('random_time', 'speed_type', 'angular_type', 'is_planet')] + \
+               [('seed', C.c_uint64), ('first_index', C.c_int64)]
 
 
 class nxc_counters(C.Structure):
@@ -212,6 +220,20 @@ class Context:
         assert soa.ndim == 2 and soa.shape[0] == 8
         self._check(self.lib.nxc_packets_upload(self._h, C.c_int64(soa.shape[1]), _p(soa)))
         self.n_packets = soa.shape[1]
+
+    def sample_packets(self, n, seed, first_index=0, download=False, **src):
+        """Draw n initial states on the device (nxc_packets_sample).  ``src``: the fields of
+        nxc_source_desc except seed/first_index (see Output.source_desc)."""
+        d = nxc_source_desc()
+        for k, v in src.items():
+            setattr(d, k, v)
+        d.seed = int(seed) & 0xffffffffffffffff
+        d.first_index = int(first_index)
+        out = np.empty((8, int(n))) if download else None
+        self._check(self.lib.nxc_packets_sample(self._h, C.byref(d), C.c_int64(int(n)),
+                                                _p(out) if download else None))
+        self.n_packets = int(n)
+        return out
 
     def image_clear(self):
         self._check(self.lib.nxc_image_clear(self._h))

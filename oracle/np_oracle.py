@@ -423,3 +423,83 @@ def los_iteration(samples, sc, dphi, outeredge, vrplanet, g_tables, unit_cm, n_i
             npack[i] = np.sum(inview)
             used[i] = rows[wtemp > 0]
     return rad, npack, included, used
+
+
+# --- counter-based RNG shared with the device sampler / surface re-emission (f-4, f-2) -----------
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon et al., SC'11; the Random123 reference): vectorised over uint32
+    arrays.  Returns four uint32 arrays."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    W0, W1 = 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & np.uint64(0xffffffff) for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint64(int(k0) & 0xffffffff)
+    k1 = np.uint64(int(k1) & 0xffffffff)
+    mask = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0 = M0*c0
+        p1 = M1*c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & mask
+        hi1, lo1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = np.uint64((int(k0) + W0) & 0xffffffff)
+        k1 = np.uint64((int(k1) + W1) & 0xffffffff)
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def philox_uniform_pairs(index, block, stream, seed):
+    """Two uniform doubles in [0, 1) per (packet index, block): counter = (index_lo, index_hi,
+    block, stream), key = (seed_lo, seed_hi); u = ((a << 32 | b) >> 11) * 2^-53."""
+    index = np.asarray(index, dtype=np.uint64)
+    r = philox4x32_10(index & np.uint64(0xffffffff), index >> np.uint64(32),
+                      np.uint64(block), np.uint64(stream), seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+    r = [x.astype(np.uint64) for x in r]
+    u0 = ((r[0] << np.uint64(32) | r[1]) >> np.uint64(11)).astype(np.float64) * 2.0**-53
+    u1 = ((r[2] << np.uint64(32) | r[3]) >> np.uint64(11)).astype(np.float64) * 2.0**-53
+    return u0, u1
+
+
+def sample_x0_philox(n, seed, first_index=0, *, endtime, exobase=1.0, sinlat0=-1.0, sinlat1=1.0,
+                     lon0=0.0, lon1=2*np.pi, vprob=2.5, vwidth=2.0, unit_km=2440.53,
+                     sinalt0=0.0, sinalt1=1.0, az0=0.0, az1=2*np.pi, random_time=0, speed_type=0,
+                     angular_type=1, is_planet=1):
+    """NumPy restatement of the device sampler (k_sample): the formulas of
+    initial_state/source_distribution.py:47-62,141-171,198-252 fed by Philox uniforms.
+    Returns X0 (n, 8)."""
+    idx = np.arange(n, dtype=np.uint64) + np.uint64(first_index)
+    ut, ulat = philox_uniform_pairs(idx, 0, 0x5a0, seed)
+    ulon, uspd = philox_uniform_pairs(idx, 1, 0x5a0, seed)
+    ualt, uaz = philox_uniform_pairs(idx, 2, 0x5a0, seed)
+    time = ut*endtime if random_time else np.zeros(n) + endtime
+    lat = np.arcsin(sinlat0 + (sinlat1 - sinlat0)*ulat)
+    lon = np.fmod(lon0 + (lon1 - lon0)*ulon, 2*np.pi)
+    sign = 1.0 if is_planet else -1.0
+    x0 = sign*exobase*np.sin(lon)*np.cos(lat)
+    y0 = -exobase*np.cos(lon)*np.cos(lat)
+    z0 = exobase*np.sin(lat)
+    if speed_type == 0:
+        v = uspd*2*vwidth + vprob - vwidth
+    else:
+        g0, g1 = philox_uniform_pairs(idx, 3, 0x5a0, seed)
+        zn = np.sqrt(-2.0*np.log(1.0 - g0))*np.cos(2*np.pi*g1)
+        v = np.zeros(n) + vprob if vwidth == 0 else zn*vwidth + vprob
+    v = v/unit_km
+    if angular_type == 0:
+        alt, az = np.zeros(n) + np.pi/2, np.zeros(n)
+    else:
+        alt = np.arcsin(ualt*(sinalt1 - sinalt0) + sinalt0)
+        az = az0 + (az1 - az0)*uaz
+    v_rad, v_t0, v_t1 = np.sin(alt), np.cos(alt)*np.cos(az), np.cos(alt)*np.sin(az)
+    rn = np.sqrt((x0*x0 + y0*y0) + z0*z0)
+    en = np.sqrt(y0*y0 + x0*x0)
+    n0, n1, n2 = -z0*x0, -z0*y0, x0*x0 + y0*y0
+    nn = np.sqrt((n0*n0 + n1*n1) + n2*n2)
+    X = np.zeros((n, 8))
+    X[:, 0] = time
+    X[:, 1], X[:, 2], X[:, 3] = x0, y0, z0
+    X[:, 4] = ((v_t0*(n0/nn) + v_t1*(y0/en)) + v_rad*(x0/rn))*v
+    X[:, 5] = ((v_t0*(n1/nn) + v_t1*(-x0/en)) + v_rad*(y0/rn))*v
+    X[:, 6] = ((v_t0*(n2/nn) + v_t1*0.0) + v_rad*(z0/rn))*v
+    X[:, 7] = 1.0
+    return X

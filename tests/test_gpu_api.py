@@ -187,3 +187,48 @@ def test_los_used_pairs_and_tiles(ctx):
     pairs = set(zip(it['used'][0].tolist(), it['used'][1].tolist()))
     ref_pairs = {(i, int(row)) for i, rows in enumerate(used) for row in rows}
     assert it['n_used'] == len(ref_pairs) and pairs == ref_pairs
+
+
+def test_device_sampler_matches_philox_oracle_and_reference_statistics(ctx):
+    """f-4: k_sample == NumPy Philox restatement (to libm rounding), is counter-addressed
+    (chunks concatenate), and is statistically the reference's source (KS tests in the spirit of
+    tests/unit_tests/Initial_state/test_spatial_distribution.py:95-143)."""
+    from scipy import stats
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    out = Output(inputs, 200000, seed=77, integrate=False, save=False, context=ctx,
+                 sampler='device')
+    X = out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values
+    ref = O.sample_x0_philox(200000, 77, **out.source_desc())
+    np.testing.assert_allclose(X, ref, rtol=1e-12, atol=1e-15)
+    a = ctx.sample_packets(1000, 77, first_index=0, download=True, **out.source_desc())
+    b = ctx.sample_packets(1000, 77, first_index=1000, download=True, **out.source_desc())
+    c = ctx.sample_packets(2000, 77, first_index=0, download=True, **out.source_desc())
+    assert np.array_equal(np.concatenate([a, b], axis=1), c)
+    # against the host sampler with NumPy's generator: same distributions
+    host = Output(inputs, 200000, seed=5, integrate=False, save=False)
+    for col in ('x', 'y', 'z', 'vx', 'vy', 'vz'):
+        assert stats.ks_2samp(out.X0[col].values, host.X0[col].values).pvalue > 1e-3, col
+    lon = (np.arctan2(X[:, 1], -X[:, 2]) + 2*np.pi) % (2*np.pi)
+    assert stats.kstest(lon, 'uniform', args=(0, 2*np.pi)).pvalue > 1e-3
+    assert stats.kstest(X[:, 3], 'uniform', args=(-1, 2)).pvalue > 1e-3          # sin(lat)
+    speed = np.linalg.norm(X[:, 4:7], axis=1)*out.unit_km
+    assert stats.kstest(speed, 'uniform', args=(0.5, 4.0)).pvalue > 1e-3
+    sinalt = np.sum(X[:, 1:4]*X[:, 4:7], axis=1)/np.linalg.norm(X[:, 4:7], axis=1)
+    assert stats.kstest(sinalt, 'uniform', args=(0, 1)).pvalue > 1e-3
+
+
+def test_device_sampled_image_matches_oracle(ctx, coracle):
+    """Streaming image from device-sampled packets == C oracle on the same (downloaded) X0."""
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    params = {'quantity': 'radiance', 'dims': '64,64'}
+    img = ModelImage(inputs, params, npackets=6000, packs_per_it=3000, seed=9, context=ctx,
+                     sampler='device')
+    out = Output(inputs, 6000, seed=9, integrate=False, save=False, context=ctx, sampler='device')
+    X0 = out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values
+    f = H.mercury_forces('Na', 1.3)
+    im = H.image_setup(f, 'radiance', dims=(64, 64))
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                              im['xedges'], im['zedges'], downcast=True)
+    ref = coracle.integrate_const(f, X0, 30., 1667, 25., img=desc, threads=4)
+    assert np.array_equal(img.packet_image, ref['counts'].astype(float))
+    np.testing.assert_allclose(img.image, ref['image']*img.atoms_per_packet, rtol=1e-11)
