@@ -112,6 +112,31 @@ int nxc_synchronize(nxc_handle *h);
 int nxc_set_forces(nxc_handle *h, const nxc_forces *f);
 int nxc_set_image(nxc_handle *h, const nxc_image_desc *d);   /* also zeroes the resident image    */
 
+/* ---- f-2: surface re-emission (particle_tracking/bouncepackets.py:39-100) --------------------------
+ * With a bounce description set, a packet that ends a step inside the planet is moved back to its
+ * impact point and re-emitted (isotropic rebound, energy accommodation to the local surface
+ * temperature through the v(T, probability) spline, sticking loss) instead of being absorbed
+ * (Output.py:398-402).  NULL restores perfect sticking.  Random numbers are Philox draws keyed
+ * by (seed; first_index + packet row, bounce number): statistically the reference's process.
+ * tx[nx], ty[ny], coef[(nx-4)*(ny-4)]: knots/coefficients of scipy's RectBivariateSpline
+ * (SurfaceInteraction.py:56) in km/s; ignored when accomfactor == 0. */
+typedef struct nxc_bounce_desc {
+    double GM;            /* R^3/s^2 (negative), for the impact speed (bouncepackets.py:59)      */
+    double unit_km;
+    double accomfactor;   /* 0 = elastic rebound at the impact speed                            */
+    double stickcoef;     /* constant sticking (used when !temp_dependent)                      */
+    double A[3];          /* temperature-dependent sticking A0 exp(A1 T) + A2                   */
+    double t0, t1;        /* surface temperature: t0 night, t0 + t1 |cos lon cos lat|^0.25 day  */
+    int32_t temp_dependent;
+    int32_t reserved;
+    int64_t nx, ny;
+    const double *tx, *ty, *coef;
+    uint64_t seed;
+} nxc_bounce_desc;
+
+int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d);
+int nxc_set_first_index(nxc_handle *h, int64_t first_index);  /* RNG counter of resident packet 0 */
+
 /* ---- a-2: state() ---------------------------------------------------------------------------- */
 int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const double *z,
               const double *vy, double *ax, double *ay, double *az, double *ioniz);

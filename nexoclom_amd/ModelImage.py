@@ -248,6 +248,8 @@ class ModelImage(ModelResult):
                 self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
                 first = False
             out.upload(ctx)
+            ctx.set_bounce(out._bounce)
+            ctx.set_first_index(done)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():
                 totals[key] = totals.get(key, 0) + v

@@ -87,11 +87,11 @@ class Output:
             else:
                 self.radpres = None
 
-            sint = inputs.surfaceinteraction
-            if ('stickcoef' not in sint.__dict__) or (sint.stickcoef != 1):
-                raise NotImplementedError(
-                    'surface re-emission (stickcoef != 1, bouncepackets.py) is outside the '
-                    'GPU hot path of this round (SURVEY.md section 8f rank 2)')
+            # surface accommodation / sticking set-up when packets do not simply stick
+            # (Output.py:130-133); None = absorbed on impact
+            from .surface import bounce_config
+            self._bounce = bounce_config(inputs, self.GM, self.unit_km, seed)
+            self._first_index = first_index
 
             if inputs.options.step_size != 0:                           # Output.py:136-141
                 time = np.ones(npackets) * inputs.options.endtime.value
@@ -242,6 +242,8 @@ class Output:
         ctx = self.context()
         ctx.set_forces(**self.forces_kwargs())
         self.upload(ctx)
+        ctx.set_bounce(self._bounce)
+        ctx.set_first_index(self._first_index)
         n = self.npackets
         if keep_trajectory:
             res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)
@@ -269,6 +271,7 @@ class Output:
     def variable_step_size_driver(self):
         """Output.py:221-366 on the GPU: final snapshot, one row per packet."""
         opt = self.inputs.options
+        assert self._bounce is None, 'Not set up'            # Output.py:312-315
         ctx = self.context()
         ctx.set_forces(**self.forces_kwargs())
         ctx.upload_soa(np.ascontiguousarray(self.X[STATE_COLS].values.T, dtype=np.float64))

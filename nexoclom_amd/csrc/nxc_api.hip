@@ -188,6 +188,10 @@ struct nxc_handle {
     unsigned *d_order = nullptr;     // packet indices by decreasing launch speed (queue order)
     size_t order_cap = 0;
     bool have_order = false;
+    int64_t first_id = 0;            // global index of resident packet 0 (RNG counter space)
+    bool have_bounce = false;
+    double *d_bounce = nullptr;      // spline knots + coefficients of the accommodation table
+    size_t bounce_cap = 0;
     DevCounters *d_ctr = nullptr;
     double *d_scratch = nullptr;     // final states / generic device scratch
     size_t scratch_cap = 0;
@@ -312,38 +316,55 @@ size_t persist_lds(size_t table_bytes)
     return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
 }
 
+template <bool IMAGE, bool BOUNCE>
+int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
+                 double *d_final, long long *d_steps)
+{
+    int grid = 1, rc;
+    auto kernel = k_const_fused<IMAGE, BOUNCE>;
+    if ((rc = prep_kernel(kernel, lds))) return rc;
+    if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, h->n_packets, &grid))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
+                       (int64_t)tables, h->n_packets, h->d_packets,
+                       h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
+                       edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
+                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr);
+    HIPCHK(hipGetLastError());
+    return end_timed(h);
+}
+
 int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, bool image,
                  double *d_final, long long *d_steps)
 {
     const size_t tables = image ? h->all_bytes : h->force_bytes;
     const size_t lds = persist_lds(tables);
-    int grid = 1, rc;
+    int rc;
     if ((rc = upload_step(h, step))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
-    if (image) {
-        if ((rc = prep_kernel(k_const_fused<true>, lds))) return rc;
-        if ((rc = persistent_grid(h, k_const_fused<true>, BLOCK_PERSIST, lds, h->n_packets, &grid)))
-            return rc;
-        if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL(k_const_fused<true>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
-                           h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter,
-                           sqrt_threshold(outeredge), d_final, d_steps, h->d_image, h->d_counts,
-                           h->d_ctr);
-    } else {
-        if ((rc = prep_kernel(k_const_fused<false>, lds))) return rc;
-        if ((rc = persistent_grid(h, k_const_fused<false>, BLOCK_PERSIST, lds, h->n_packets,
-                                  &grid)))
-            return rc;
-        if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL(k_const_fused<false>, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream,
-                           h->F, h->d_blob, (int64_t)tables, h->n_packets, h->d_packets,
-                           h->have_order ? h->d_order : (const unsigned *)nullptr, n_iter,
-                           sqrt_threshold(outeredge), d_final, d_steps, (double *)nullptr,
-                           (unsigned long long *)nullptr, h->d_ctr);
-    }
+    const double edge2 = sqrt_threshold(outeredge);
+    if (image)
+        return h->have_bounce ? launch_fused<true, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
+                              : launch_fused<true, false>(h, tables, lds, n_iter, edge2, d_final, d_steps);
+    return h->have_bounce ? launch_fused<false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
+                          : launch_fused<false, false>(h, tables, lds, n_iter, edge2, d_final, d_steps);
+}
+
+template <bool IMAGE, bool BOUNCE>
+int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double *d_traj,
+                int64_t nrec, double *d_final, long long *d_steps)
+{
+    const int64_t n = h->n_packets;
+    auto kernel = k_const_traj<IMAGE, BOUNCE>;
+    int rc = prep_kernel(kernel, lds);
+    if (rc) return rc;
+    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F, h->d_blob,
+                       (int64_t)lds, n, h->d_packets, h->first_id, n_iter, edge2, d_traj, nrec,
+                       d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
+                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr);
     HIPCHK(hipGetLastError());
-    return end_timed(h);
+    return NXC_OK;
 }
 
 }  // namespace
@@ -407,7 +428,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
-                    h->d_steps, h->d_reduce, h->d_order};
+                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -516,6 +537,45 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     int rc = upload_blob(h);
     if (rc) return rc;
     return nxc_image_clear(h);
+}
+
+int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (!d) {                       // back to perfect sticking
+        h->have_bounce = false;
+        return NXC_OK;
+    }
+    if (d->nx < 8 || d->ny < 8 || !d->tx || !d->ty || !d->coef || !(d->unit_km > 0) ||
+        d->accomfactor < 0 || d->accomfactor > 1 || d->stickcoef < 0 || d->stickcoef > 1)
+        return fail(NXC_ERR_ARG, "bad nxc_bounce_desc");
+    const size_t ncoef = (size_t)(d->nx - 4) * (size_t)(d->ny - 4);
+    const size_t total = (size_t)d->nx + (size_t)d->ny + ncoef;
+    int rc = ensure(reinterpret_cast<void **>(&h->d_bounce), &h->bounce_cap, total * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_bounce, d->tx, (size_t)d->nx * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bounce + d->nx, d->ty, (size_t)d->ny * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_bounce + d->nx + d->ny, d->coef, ncoef * 8, hipMemcpyHostToDevice, h->stream));
+    BounceK &B = h->header.B;
+    B.GM = d->GM; B.unit_km = d->unit_km; B.accom = d->accomfactor; B.stickcoef = d->stickcoef;
+    B.A0 = d->A[0]; B.A1 = d->A[1]; B.A2 = d->A[2]; B.t0 = d->t0; B.t1 = d->t1;
+    B.temp_dependent = d->temp_dependent ? 1 : 0; B.nx = (int)d->nx; B.ny = (int)d->ny;
+    B.seed = d->seed;
+    B.tx = h->d_bounce; B.ty = h->d_bounce + d->nx; B.coef = h->d_bounce + d->nx + d->ny;
+    h->have_bounce = true;
+    if (h->d_blob)
+        HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, B), &h->header.B, sizeof(BounceK),
+                              hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_set_first_index(nxc_handle *h, int64_t first_index)
+{
+    if (!h || first_index < 0) return fail(NXC_ERR_ARG, "bad arguments");
+    h->first_id = first_index;
+    return NXC_OK;
 }
 
 int nxc_image_clear(nxc_handle *h)
@@ -675,6 +735,7 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     h->n_packets = n;
+    h->first_id = 0;
     return NXC_OK;
 }
 
@@ -733,6 +794,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     h->n_packets = n;
+    h->first_id = d->first_index;
     const double vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
                                             : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
     if ((rc = order_on_device(h, vmax * vmax))) return rc;
@@ -798,25 +860,13 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
         if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
         if (e == hipSuccess) {
-            if (image) {
-                rc = prep_kernel(k_const_traj<true>, lds);
-                if (!rc)
-                    hipLaunchKernelGGL(k_const_traj<true>, dim3(grid), dim3(NXC_BLOCK), lds,
-                                       h->stream, h->F, h->d_blob,
-                                       (int64_t)lds, n, h->d_packets, n_iter, sqrt_threshold(outeredge),
-                                       d_traj,
-                                       nrec, d_final, d_steps, h->d_image, h->d_counts, h->d_ctr);
-            } else {
-                rc = prep_kernel(k_const_traj<false>, lds);
-                if (!rc)
-                    hipLaunchKernelGGL(k_const_traj<false>, dim3(grid), dim3(NXC_BLOCK), lds,
-                                       h->stream, h->F, h->d_blob,
-                                       (int64_t)lds, n, h->d_packets, n_iter, sqrt_threshold(outeredge),
-                                       d_traj,
-                                       nrec, d_final, d_steps, (double *)nullptr,
-                                       (unsigned long long *)nullptr, h->d_ctr);
-            }
-            if (!rc) e = hipGetLastError();
+            const double edge2 = sqrt_threshold(outeredge);
+            if (image)
+                rc = h->have_bounce ? launch_traj<true, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
+                                    : launch_traj<true, false>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
+            else
+                rc = h->have_bounce ? launch_traj<false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
+                                    : launch_traj<false, false>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
         }
         if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
         if (e == hipSuccess && !rc) {

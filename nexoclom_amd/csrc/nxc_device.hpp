@@ -250,24 +250,7 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
     s[7] = nxc_exp(lf);
 }
 
-// Post-step tests with stickcoef == 1.  Constant driver: Output.py:395-416 (r = |x|); variable
-// driver: Output.py:308-324, which compares r^2 with 1 AND with outeredge (reference quirk).
-// (sqrt(r2) - 1) < 0  <=>  r2 < 1 for a correctly rounded sqrt.
-// `edge2` is the host-computed threshold on r^2: for the constant driver the largest double whose
-// correctly rounded square root is <= outeredge (so r2 > edge2  <=>  sqrt(r2) > outeredge), for
-// the variable driver outeredge itself.
-NXC_DEV void apply_fate(double (&s)[8], double edge2)
-{
-    const double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
-    if (r2 < 1.0) s[7] = 0.0;
-    if (r2 > edge2) s[7] = 0.0;
-    if (s[7] < 1e-10) s[7] = 0.0;
-    if (s[7] == 0.0) s[0] = 0.0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Image: data_simulation/ModelImage.py:242-269, ModelResult.py:140-170, math/histogram.py:32-36
-// ---------------------------------------------------------------------------------------------
+// ---- launch constants kept in LDS ----------------------------------------------------------------
 struct ImageK {            // kernel-argument scalars of nxc_image_desc
     double M[9];
     double vrplanet, apix_cm2;
@@ -282,9 +265,20 @@ struct ImageK {            // kernel-argument scalars of nxc_image_desc
 // LDS block instead of in scalar registers: together with the force constants they would exceed
 // the 102 SGPRs of a wave, and every spilled SGPR costs v_readlane/v_writelane VALU slots in a
 // VALU-bound kernel.  (StepW is defined above; ImageK here.)
+// Surface re-emission constants (particle_tracking/bouncepackets.py; read only when a packet
+// hits the surface).  tx/ty/coef: knots and coefficients of the bicubic spline v(T, p) in global
+// memory (FITPACK layout: coef[(nx-4) x (ny-4)] row-major).
+struct BounceK {
+    double GM, unit_km, accom, stickcoef, A0, A1, A2, t0, t1;
+    int temp_dependent, nx, ny, pad_;
+    unsigned long long seed;
+    const double *tx, *ty, *coef;
+};
+
 struct LdsHeader {
     ImageK G;
     StepW W;
+    BounceK B;
 };
 constexpr int NXC_HEADER_BYTES = (int)((sizeof(LdsHeader) + 31) & ~size_t(31));
 
@@ -292,6 +286,168 @@ NXC_DEV const LdsHeader &lds_header()
 {
     return *reinterpret_cast<const LdsHeader *>(nxc_lds);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Surface re-emission: particle_tracking/bouncepackets.py:5-100, SurfaceInteraction.py:10-61,
+// initial_state/surface_temperature.py:4-19.  Uniforms come from Philox keyed by (seed; packet
+// id, bounce number): the reference draws them from its sequential generator, so parity with
+// it is statistical; parity with the oracle's restatement (same uniforms) is to libm rounding.
+// ---------------------------------------------------------------------------------------------
+NXC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                           unsigned k1, unsigned (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
+        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two uniform doubles in [0,1): ((a << 32 | b) >> 11) * 2^-53
+NXC_DEV void philox_pair(unsigned long long index, unsigned block, unsigned stream,
+                         unsigned long long seed, double &u0, double &u1)
+{
+    unsigned r[4];
+    philox4x32_10((unsigned)index, (unsigned)(index >> 32), block, stream, (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    u0 = (double)((((unsigned long long)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
+    u1 = (double)((((unsigned long long)r[2] << 32) | r[3]) >> 11) * 0x1p-53;
+}
+
+constexpr unsigned NXC_STREAM_SOURCE = 0x5a0u;
+constexpr unsigned NXC_STREAM_BOUNCE = 0xb0cu;
+
+// The four non-zero cubic B-spline basis values at x in knot interval l (FITPACK fpbspl).
+NXC_DEV void bspline_basis3(const double *__restrict__ t, int l, double x, double (&h)[4])
+{
+    h[0] = 1.0; h[1] = h[2] = h[3] = 0.0;
+#pragma unroll
+    for (int j = 1; j <= 3; j++) {
+        double hh[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) hh[i] = h[i];
+        h[0] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i < j) {
+                const int li = l + i + 1, lj = li - j;
+                const double f = hh[i] / (t[li] - t[lj]);
+                h[i] += f * (t[li] - x);
+                h[i + 1] = f * (x - t[lj]);
+            }
+        }
+    }
+}
+
+NXC_DEV int knot_interval(const double *__restrict__ t, int n, double x)
+{
+    int lo = 3, hi = n - 4;                     // t[lo] <= x < t[hi] (x clamped to [t[3], t[n-4]])
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (x >= t[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// scipy RectBivariateSpline(...).ev(x, y) for kx = ky = 3 (FITPACK bispev)
+NXC_DEV double bispev3(const BounceK &B, double x, double y)
+{
+    x = __builtin_fmin(__builtin_fmax(x, B.tx[3]), B.tx[B.nx - 4]);
+    y = __builtin_fmin(__builtin_fmax(y, B.ty[3]), B.ty[B.ny - 4]);
+    const int l = knot_interval(B.tx, B.nx, x), m = knot_interval(B.ty, B.ny, y);
+    double hx[4], hy[4];
+    bspline_basis3(B.tx, l, x, hx);
+    bspline_basis3(B.ty, m, y, hy);
+    const int ncy = B.ny - 4;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) s += B.coef[(l - 3 + i) * ncy + (m - 3 + j)] * hx[i] * hy[j];
+    return s;
+}
+
+// One impact: move the packet back to the surface along its velocity, re-emit it.
+NXC_DEV void bounce_packet(const BounceK &B, double (&s)[8], double r2, unsigned long long id,
+                           int &nbounce)
+{
+    const double TWO_PI = 6.283185307179586;
+    double x = s[1], y = s[2], z = s[3];
+    const double vx = s[4], vy = s[5], vz = s[6];
+    const double a = (vx * vx + vy * vy) + vz * vz;                   // :45-52
+    const double b = 2 * ((x * vx + y * vy) + z * vz);
+    const double c = r2 - 1.;
+    const double sq = nxc_sqrt(b * b - 4 * a * c);
+    const double t = __builtin_fmin((-b - sq) / (2 * a), (-b + sq) / (2 * a));
+    x = x + vx * t; y = y + vy * t; z = z + vz * t;                     // :55
+    const double r = nxc_sqrt(r2);
+    double v_old2 = a + 2 * B.GM * (1. / r - 1);                        // :59-61
+    v_old2 = v_old2 < 0 ? 0. : v_old2;
+    double u_alt, u_az, u_p, unused;
+    philox_pair(id, 2u * (unsigned)nbounce, NXC_STREAM_BOUNCE, B.seed, u_alt, u_az);
+    philox_pair(id, 2u * (unsigned)nbounce + 1u, NXC_STREAM_BOUNCE, B.seed, u_p, unused);
+    nbounce++;
+    const double alt = asin(u_alt), az = TWO_PI * u_az;                 // :9-18
+    const double v_rad = sin(alt), v_t0 = cos(alt) * cos(az), v_t1 = cos(alt) * sin(az);
+    const double rn = nxc_sqrt((x * x + y * y) + z * z);                // :23-33
+    const double en = nxc_sqrt(y * y + x * x);
+    const double n0 = -z * x, n1 = -z * y, n2 = x * x + y * y;
+    const double nn = nxc_sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+    const double dx = (v_t0 * (n0 / nn) + v_t1 * (y / en)) + v_rad * (x / rn);
+    const double dy = (v_t0 * (n1 / nn) + v_t1 * (-x / en)) + v_rad * (y / rn);
+    const double dz = (v_t0 * (n2 / nn) + v_t1 * 0.0) + v_rad * (z / rn);
+    const double lonhit = fmod(atan2(x, -y) + TWO_PI, TWO_PI);          // :68-69
+    const double lathit = asin(z);
+    double tsurf = B.t0;                                                // surface_temperature.py:12-17
+    if (lonhit <= 1.5707963267948966 || lonhit >= 4.71238898038469)
+        tsurf = B.t0 + B.t1 * nxc_sqrt(nxc_sqrt(__builtin_fabs(cos(lonhit) * cos(lathit))));
+    double v_new;
+    if (B.accom == 0.0) {
+        v_new = nxc_sqrt(v_old2);                                       // :65-66
+    } else {
+        const double v_emit = bispev3(B, tsurf, u_p) / B.unit_km;       // :71-75
+        v_new = nxc_sqrt(v_emit * v_emit * B.accom + v_old2 * (1 - B.accom));   // :77-78
+    }
+    s[1] = x; s[2] = y; s[3] = z;
+    s[4] = dx * v_new; s[5] = dy * v_new; s[6] = dz * v_new;            // :80
+    if (B.temp_dependent) {                                             // :83-89, SurfaceInteraction.py:13-20
+        double st = B.A0 * exp(B.A1 * tsurf) + B.A2;
+        st = st > 1. ? 1. : (st < 0. ? 0. : st);
+        s[7] *= (1 - st);
+    } else if (B.stickcoef > 0) {
+        s[7] *= (1 - B.stickcoef);                                      // :92-93
+    }
+}
+
+// Post-step tests with stickcoef == 1.  Constant driver: Output.py:395-416 (r = |x|); variable
+// driver: Output.py:308-324, which compares r^2 with 1 AND with outeredge (reference quirk).
+// (sqrt(r2) - 1) < 0  <=>  r2 < 1 for a correctly rounded sqrt.
+// `edge2` is the host-computed threshold on r^2: for the constant driver the largest double whose
+// correctly rounded square root is <= outeredge (so r2 > edge2  <=>  sqrt(r2) > outeredge), for
+// the variable driver outeredge itself.
+// With BOUNCE a packet that hits the surface is re-emitted instead of absorbed (Output.py:398-402);
+// the escape test still uses the pre-impact radius, as the reference's tempR does.
+template <bool BOUNCE>
+NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int &nbounce)
+{
+    const double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
+    if (r2 < 1.0) {
+        if (BOUNCE) bounce_packet(lds_header().B, s, r2, id, nbounce);
+        else s[7] = 0.0;
+    }
+    if (r2 > edge2) s[7] = 0.0;
+    if (s[7] < 1e-10) s[7] = 0.0;
+    if (s[7] == 0.0) s[0] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image: data_simulation/ModelImage.py:242-269, ModelResult.py:140-170, math/histogram.py:32-36
+// ---------------------------------------------------------------------------------------------
 
 // Launch constants of the image path that are worth a register: read from the LDS header once
 // per thread before the step loop (the compiler cannot hoist LDS loads over the loop's LDS

@@ -104,11 +104,11 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
 // ---------------------------------------------------------------------------------------------
 // Lock-step driver with trajectory output.  traj is pre-zeroed: dead packets leave zero records,
 // like the reference's `results` (Output.py:376).
-template <bool IMAGE>
+template <bool IMAGE, bool BOUNCE>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
-             int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t n_iter,
-             double edge2, double *__restrict__ traj, int64_t nrec,
+             int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t first_id,
+             int64_t n_iter, double edge2, double *__restrict__ traj, int64_t nrec,
              double *__restrict__ final_out, long long *__restrict__ steps_out,
              double *__restrict__ image, unsigned long long *__restrict__ counts,
              DevCounters *__restrict__ ctr)
@@ -132,9 +132,10 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
                                       my_nonfinite);
         }
         long long k = 0;
+        int nbounce = 0;
         while (alive && k < n_iter) {
             rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-            apply_fate(s, edge2);
+            apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
             k++; my_steps++;
             if (k < nrec) {
 #pragma unroll
@@ -227,11 +228,11 @@ struct WaveQueue {
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
-template <bool IMAGE>
+template <bool IMAGE, bool BOUNCE>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
-              const unsigned *__restrict__ order, int64_t n_iter,
+              const unsigned *__restrict__ order, int64_t first_id, int64_t n_iter,
               double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ image,
               unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr)
@@ -245,11 +246,12 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
     bool has = false;
     long long id = -1, k = 0;
+    int nbounce = 0;
     double s[8], d[8];
     for (;;) {
         const long long got = q.refill(!has, &ctr->queue_head, n, soa0, order, stage_off, s);
         if (got >= 0) {
-            id = got; k = 0; has = true;
+            id = got; k = 0; has = true; nbounce = 0;
             if (IMAGE && s[7] > 0.0) {
                 my_samples++;
                 my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
@@ -261,7 +263,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             bool done = !(s[7] > 0.0) || k >= n_iter;
             if (!done) {
                 rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-                apply_fate(s, edge2);
+                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
                 k++; my_steps++;
                 if (s[7] > 0.0) {
                     if (IMAGE) {
@@ -349,7 +351,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                         double hold = h;
                         if (e < 1e-7) { e = 1.0; hold = h * 10; }
                         if (e < 1.0) {
-                            apply_fate(t, outeredge);
+                            { int nb_ = 0; apply_fate<false>(t, outeredge, 0ull, nb_); }
 #pragma unroll
                             for (int c = 0; c < 8; c++) s[c] = t[c];
                         } else {
@@ -534,34 +536,6 @@ struct SourceK {
     unsigned long long seed;
     long long first_index;
 };
-
-NXC_DEV void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                           unsigned k1, unsigned (&out)[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0;
-        const unsigned hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// two uniform doubles in [0,1): ((a << 32 | b) >> 11) * 2^-53
-NXC_DEV void philox_pair(unsigned long long index, unsigned block, unsigned stream,
-                         unsigned long long seed, double &u0, double &u1)
-{
-    unsigned r[4];
-    philox4x32_10((unsigned)index, (unsigned)(index >> 32), block, stream, (unsigned)seed,
-                  (unsigned)(seed >> 32), r);
-    u0 = (double)((((unsigned long long)r[0] << 32) | r[1]) >> 11) * 0x1p-53;
-    u1 = (double)((((unsigned long long)r[2] << 32) | r[3]) >> 11) * 0x1p-53;
-}
-
-constexpr unsigned NXC_STREAM_SOURCE = 0x5a0u;
 
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_sample(SourceK K, int64_t n, double *__restrict__ soa)

@@ -22,7 +22,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_image_download', 'nxc_counters_get', 'nxc_last_kernel_ms', 'nxc_integrate_const',
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
-           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample')
+           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
+           'nxc_set_bounce', 'nxc_set_first_index')
 
 
 class HipError(RuntimeError):
@@ -58,6 +59,14 @@ class nxc_source_desc(C.Structure):
                  'unit_km', 'sinalt0', 'sinalt1', 'az0', 'az1')] + \
                [(k, C.c_int32) for k in ('random_time', 'speed_type', 'angular_type', 'is_planet')] + \
                [('seed', C.c_uint64), ('first_index', C.c_int64)]
+
+
+class nxc_bounce_desc(C.Structure):
+    _fields_ = [('GM', C.c_double), ('unit_km', C.c_double), ('accomfactor', C.c_double),
+                ('stickcoef', C.c_double), ('A', C.c_double*3), ('t0', C.c_double),
+                ('t1', C.c_double), ('temp_dependent', C.c_int32), ('reserved', C.c_int32),
+                ('nx', C.c_int64), ('ny', C.c_int64), ('tx', _dp), ('ty', _dp), ('coef', _dp),
+                ('seed', C.c_uint64)]
 
 
 class nxc_counters(C.Structure):
@@ -187,6 +196,26 @@ class Context:
                 d.line_n[k], d.line_v[k], d.line_g[k] = len(v), _p(v), _p(g)
         self._check(self.lib.nxc_set_image(self._h, C.byref(d)))
         self.image_shape = (int(d.nx), int(d.nz))
+
+    def set_bounce(self, cfg):
+        """cfg: dict from nexoclom_amd.surface.bounce_config, or None for perfect sticking."""
+        if cfg is None:
+            self._check(self.lib.nxc_set_bounce(self._h, None))
+            return
+        d = nxc_bounce_desc()
+        d.GM, d.unit_km = cfg['GM'], cfg['unit_km']
+        d.accomfactor, d.stickcoef = cfg['accomfactor'], cfg['stickcoef']
+        d.A = (C.c_double*3)(*cfg['A'])
+        d.t0, d.t1 = cfg['t0'], cfg['t1']
+        d.temp_dependent = int(cfg['temp_dependent'])
+        tx, ty, coef = _f64(cfg['tx']), _f64(cfg['ty']), _f64(cfg['coef'])
+        d.nx, d.ny = len(tx), len(ty)
+        d.tx, d.ty, d.coef = _p(tx), _p(ty), _p(coef)
+        d.seed = int(cfg['seed']) & 0xffffffffffffffff
+        self._check(self.lib.nxc_set_bounce(self._h, C.byref(d)))
+
+    def set_first_index(self, first_index):
+        self._check(self.lib.nxc_set_first_index(self._h, C.c_int64(int(first_index))))
 
     # -- a-2 / a-1 --------------------------------------------------------------------------
     def state(self, x, y, z, vy):

@@ -503,3 +503,95 @@ def sample_x0_philox(n, seed, first_index=0, *, endtime, exobase=1.0, sinlat0=-1
     X[:, 6] = ((v_t0*(n2/nn) + v_t1*0.0) + v_rad*(z0/rn))*v
     X[:, 7] = 1.0
     return X
+
+
+# --- surface re-emission ----------------------------------------------
+
+def bounce_packets(Xn, r0, hit, cfg, ids, nbounce):
+    """particle_tracking/bouncepackets.py:5-100 with the uniforms taken from the counter-based
+    generator the kernels use (packet id, bounce number) instead of the reference's sequential
+    PCG64 stream: stream 0xb0c, block 2*nbounce -> (sinalt, az/2pi), block 2*nbounce+1 ->
+    (probability, -).  cfg: dict from nexoclom_amd.surface.bounce_config (GM, unit_km,
+    accomfactor, temp_dependent, stickcoef, A, t0, t1, tpow, surf, seed).  Modifies Xn rows in
+    ``hit`` in place and increments nbounce there."""
+    if not np.any(hit):
+        return
+    X = Xn[hit]
+    r = r0[hit]
+    a = np.sum(X[:, 4:7]**2, axis=1)
+    b = 2*np.sum(X[:, 1:4]*X[:, 4:7], axis=1)
+    c = np.sum(X[:, 1:4]**2, axis=1) - 1.
+    t0 = (-b - np.sqrt(b**2 - 4*a*c))/(2*a)
+    t1 = (-b + np.sqrt(b**2 - 4*a*c))/(2*a)
+    t = np.minimum(t0, t1)
+    X[:, 1:4] = X[:, 1:4] + X[:, 4:7]*t[:, None]
+    assert np.all(np.isclose(np.linalg.norm(X[:, 1:4], axis=1), 1.))
+    PE = 2*cfg['GM']*(1./r - 1)
+    v_old2 = a + PE
+    v_old2[v_old2 < 0] = 0.
+    pid, nb = ids[hit], nbounce[hit]
+    u_alt, u_az, u_p = np.empty(len(pid)), np.empty(len(pid)), np.empty(len(pid))
+    for k in np.unique(nb):
+        m = nb == k
+        u_alt[m], u_az[m] = philox_uniform_pairs(pid[m], 2*int(k), 0xb0c, cfg['seed'])
+        u_p[m], _ = philox_uniform_pairs(pid[m], 2*int(k)+1, 0xb0c, cfg['seed'])
+    alt = np.arcsin(u_alt)
+    az = 2*np.pi*u_az
+    v_rad, v_t0, v_t1 = np.sin(alt), np.cos(alt)*np.cos(az), np.cos(alt)*np.sin(az)
+    x = X[:, 1:4]
+    rad = x/np.linalg.norm(x, axis=1)[:, None]
+    east = np.stack([x[:, 1], -x[:, 0], np.zeros(len(pid))], 1)
+    east /= np.linalg.norm(east, axis=1)[:, None]
+    north = np.stack([-x[:, 2]*x[:, 0], -x[:, 2]*x[:, 1], x[:, 0]**2 + x[:, 1]**2], 1)
+    north /= np.linalg.norm(north, axis=1)[:, None]
+    direction = v_t0[:, None]*north + v_t1[:, None]*east + v_rad[:, None]*rad
+    lonhit = (np.arctan2(X[:, 1], -X[:, 2]) + 2*np.pi) % (2*np.pi)
+    lathit = np.arcsin(X[:, 3])
+    tsurf = np.zeros(len(pid)) + cfg['t0']
+    day = (lonhit <= np.pi/2) | (lonhit >= 3*np.pi/2)
+    tsurf[day] = cfg['t0'] + cfg['t1']*np.abs(np.cos(lonhit[day])*np.cos(lathit[day]))**cfg['tpow']
+    if cfg['accomfactor'] == 0:
+        v_new = np.sqrt(v_old2)
+    else:
+        v_emit = cfg['surf'].v_interp(tsurf, u_p)/cfg['unit_km']
+        af = cfg['accomfactor']
+        v_new = np.sqrt(v_emit**2*af + v_old2*(1-af))
+    X[:, 4:7] = direction*v_new[:, None]
+    if cfg['temp_dependent']:
+        A = cfg['A']
+        stick = A[0]*np.exp(A[1]*tsurf) + A[2]
+        stick = np.clip(stick, 0., 1.)
+        X[:, 7] *= (1 - stick)
+    elif cfg['stickcoef'] > 0:
+        X[:, 7] *= (1 - cfg['stickcoef'])
+    Xn[hit] = X
+    nbounce[hit] += 1
+
+
+def constant_step_driver_bounce(f: Forces, X0, endtime, step, outeredge, cfg, first_index=0):
+    """constant_step_driver with surface re-emission in place of sticking (Output.py:398-402)."""
+    n = X0.shape[0]
+    nsteps, _ = n_output_steps(endtime, step)
+    results = np.zeros((n, 8, nsteps))
+    results[:, :, 0] = X0
+    ids = np.arange(n, dtype=np.uint64) + np.uint64(first_index)
+    nbounce = np.zeros(n, dtype=np.int64)
+    curtime, ct, work = float(endtime), 1, 0
+    alive = results[:, 7, 0] > 0
+    while curtime > 0 and alive.any():
+        idx = np.nonzero(alive)[0]
+        Xn, _ = rk5(f, results[idx, :, ct-1], np.zeros(len(idx)) + step)
+        work += len(idx)
+        r0 = np.sqrt((Xn[:, 1]*Xn[:, 1] + Xn[:, 2]*Xn[:, 2]) + Xn[:, 3]*Xn[:, 3])
+        hit = (r0 - 1.) < 0
+        nb = nbounce[idx]
+        bounce_packets(Xn, r0, hit, cfg, ids[idx], nb)
+        nbounce[idx] = nb
+        Xn[r0 > outeredge, 7] = 0
+        Xn[Xn[:, 7] < 1e-10, 7] = 0.
+        Xn[Xn[:, 7] == 0, 0] = 0.
+        results[idx, :, ct] = Xn
+        alive = results[:, 7, ct] > 0
+        ct += 1
+        curtime -= step
+    return results, nbounce, work

@@ -232,3 +232,77 @@ def test_device_sampled_image_matches_oracle(ctx, coracle):
     ref = coracle.integrate_const(f, X0, 30., 1667, 25., img=desc, threads=4)
     assert np.array_equal(img.packet_image, ref['counts'].astype(float))
     np.testing.assert_allclose(img.image, ref['image']*img.atoms_per_packet, rtol=1e-11)
+
+
+@pytest.mark.parametrize('infile', ['Bounce.const.input', 'Bounce.tempdep.input'])
+def test_surface_reemission_matches_oracle(ctx, infile):
+    """f-2: packets that hit the surface are re-emitted (bouncepackets.py).  GPU vs the NumPy
+    restatement driven by the same Philox uniforms: trajectories to 1e-8, identical bounce
+    bookkeeping; plus the physics the reference intends (packets stay above the surface, frac
+    only drops by the sticking factor at an impact)."""
+    from nexoclom_amd.surface import bounce_config
+    inputs = Input(os.path.join(HERE, 'inputfiles', infile))
+    n = 400
+    out = Output(inputs, n, compress=False, seed=31, context=ctx, save=False)
+    nsteps = out.nsteps
+    traj = np.stack([out.X[c].values.reshape(n, nsteps) for c in
+                     ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']], axis=1)   # (n, 8, nsteps)
+    f = H.mercury_forces('Na', float(inputs.geometry.taa), True, inputs.forces.radpres, 0.0)
+    X0 = out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values.astype(float)
+    cfg = bounce_config(inputs, f.GM, f.R_km, 31)
+    res, nb, work = O.constant_step_driver_bounce(f, X0, inputs.options.endtime.value, 30.,
+                                                  inputs.options.outeredge, cfg)
+    assert nb.sum() > n                     # most packets come back down at least once
+    assert out.counters['particle_steps'] == work
+    np.testing.assert_allclose(traj, res, rtol=1e-8, atol=1e-10)
+    r = np.sqrt(traj[:, 1]**2 + traj[:, 2]**2 + traj[:, 3]**2)
+    alive = traj[:, 7] > 0
+    assert np.all(r[alive] > 1 - 1e-9)      # never left inside the planet
+    # the fused (lane-refill) kernel re-emits identically: same final states as the trajectory run
+    ctx.upload_packets(X0)
+    ctx.set_bounce(cfg)
+    ctx.set_first_index(0)
+    g = ctx.integrate_const(30., nsteps - 1, inputs.options.outeredge, want_final=True,
+                            want_steps=True)
+    last = np.minimum(g['steps'], nsteps - 1)
+    assert np.array_equal(g['final'], traj[np.arange(n), :, last])
+    ctx.set_bounce(None)
+
+
+def test_reemission_statistics_follow_the_reference_process(ctx):
+    """Rebound directions are cosine-weighted in altitude and uniform in azimuth
+    (bouncepackets.py:8-18), speeds follow the accommodation law (:77-78): checked on the first
+    bounce of many packets dropped onto the day side."""
+    from scipy import stats
+    from nexoclom_amd.surface import bounce_config
+    inputs = Input(os.path.join(HERE, 'inputfiles', 'Bounce.const.input'))
+    inputs.surfaceinteraction.accomfactor = 0.0          # elastic: |v| after = impact speed
+    n = 40000
+    rng = np.random.default_rng(4)
+    X0 = np.zeros((n, 8)); X0[:, 0] = 9000.; X0[:, 7] = 1.0
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    X0[:, 1:4] = d*1.001                                  # just above the surface, moving down
+    X0[:, 4:7] = -d*1.5/2440.53
+    out = Output(inputs, n, seed=1, integrate=False, save=False, context=ctx)
+    cfg = bounce_config(inputs, float(out.GM), out.unit_km, 123)
+    ctx.set_forces(**out.forces_kwargs())
+    ctx.upload_packets(X0); ctx.set_bounce(cfg); ctx.set_first_index(0)
+    g = ctx.integrate_const(30., 1, 15., nrec=2)
+    ctx.set_bounce(None)
+    x1, v1, f1 = g['traj'][1:4, 1].T, g['traj'][4:7, 1].T, g['traj'][7, 1]
+    assert np.allclose(np.linalg.norm(x1, axis=1), 1.0, atol=1e-12)      # put back on the surface
+    assert np.all((f1 <= 0.7 + 1e-12) & (f1 > 0.69))    # (1 - stickcoef) x one step of photo-loss
+    speed = np.linalg.norm(v1, axis=1)
+    sinalt = np.sum(x1*v1, axis=1)/speed
+    assert stats.kstest(sinalt, 'uniform', args=(0, 1)).pvalue > 1e-3
+    east = np.stack([x1[:, 1], -x1[:, 0], np.zeros(n)], 1)
+    east /= np.linalg.norm(east, axis=1)[:, None]
+    north = np.cross(x1, east)
+    az = (np.arctan2(np.sum(v1*east, axis=1), np.sum(v1*north, axis=1)) + 2*np.pi) % (2*np.pi)
+    assert stats.kstest(az, 'uniform', args=(0, 2*np.pi)).pvalue > 1e-3
+    # elastic rebound: kinetic energy at the surface = impact energy (bouncepackets.py:59-66)
+    GM = float(out.GM)
+    r_in = np.linalg.norm(X0[:, 1:4] + 0, axis=1)
+    e_in = 0.5*np.sum(X0[:, 4:7]**2, axis=1) + GM/r_in
+    e_out = 0.5*speed**2 + GM/1.0
+    assert np.allclose(e_out, e_in, rtol=2e-3)           # one RK step of free fall in between

@@ -158,8 +158,24 @@ def test_uniform_surface_sampling_statistics():
     assert out.loss_info.photo == 1/7200.
 
 
-def test_bounce_and_moons_are_refused():
-    inp = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
-    inp.surfaceinteraction.stickcoef = 0.5
-    with pytest.raises(NotImplementedError):
-        Output(inp, 10, seed=1, integrate=False, save=False)
+def test_surface_interaction_tables():
+    """SurfaceInteraction.py:10-61 restated: temperature model, sticking law, v(T, p) table."""
+    from nexoclom_amd.surface import SurfaceInteraction, bounce_config, surface_temperature
+    inp = Input(os.path.join(HERE, 'inputfiles', 'Bounce.tempdep.input'))
+    t = surface_temperature(inp.geometry, np.array([0., np.pi/2, np.pi, 0.]),
+                            np.array([0., 0., 0., np.pi/3]))
+    t1 = 600 + 125*(np.cos(1.3) - 1)/2
+    assert np.allclose(t, [100 + t1, 100 + t1*np.cos(np.pi/2)**0.25, 100, 100 + t1*0.5**0.25])
+    surf = SurfaceInteraction(inp)
+    st = surf.stickcoef(np.array([0., np.pi]), np.array([0., 0.]))
+    A = inp.surfaceinteraction.A
+    assert np.allclose(st, np.clip(A[0]*np.exp(A[1]*np.array([100 + t1, 100.])) + A[2], 0, 1))
+    assert surf.probgrid.shape == (201, 101) and np.all(np.diff(surf.probgrid, axis=1) >= 0)
+    assert np.all(np.diff(surf.probgrid[:, 50]) > 0)          # hotter surface, faster atoms
+    # median emission speed ~ 1.09 v_th for the v^3 exp(-v^2/vth^2) flux distribution
+    vth = np.sqrt(2*surf.temperature*1.380649e-23/(22.98976928*1.66053906660e-27))/1e3
+    assert np.allclose(surf.v_interp(surf.temperature, np.full(201, 0.5))/vth, 1.2958, atol=0.02)
+    cfg = bounce_config(inp, -1.5e-6, 2440.53, 7)
+    assert cfg['temp_dependent'] == 1 and cfg['accomfactor'] == 0.2 and len(cfg['tx']) == 205
+    inp2 = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    assert bounce_config(inp2, -1.5e-6, 2440.53, 7) is None
