@@ -121,14 +121,15 @@ def main():
 
     reduce_mode = 'none'
     if world > 1:
-        cp.init_rccl(ctx)
-        reduce_mode = 'rccl-allreduce'
+        reduce_mode = 'rccl-allreduce' if cp.init_rccl(ctx) else 'gloo-host-fallback'
 
     def one_step():
         ctx.image_clear()
         ctx.integrate_const_async(opt.step_size, n_iter, opt.outeredge, image=True)
-        if world > 1:
+        if reduce_mode == 'rccl-allreduce':
             ctx.image_allreduce()
+        elif world > 1:          # only if RCCL could not be brought up: sum on the host
+            cp.allreduce_images_host(*ctx.image_download())
 
     for _ in range(args.warmup):
         one_step()
@@ -193,7 +194,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
-    if world > 1:
+    if reduce_mode == 'rccl-allreduce':
         ctx.comm_destroy()
     ctx.close()
     cp.close()

@@ -34,6 +34,9 @@ class ControlPlane:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29511')
+            if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost'):
+                # single node: keep gloo on the loopback device (the hostname may not resolve)
+                os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
             if not dist.is_initialized():
                 dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             self.dist, self.torch = dist, torch
@@ -72,11 +75,25 @@ class ControlPlane:
 
     def init_rccl(self, ctx):
         """Create the RCCL communicator on a hip_api.Context (rank 0's unique id is broadcast
-        over the control plane)."""
+        over the control plane).  Returns True when every rank has a communicator; on False the
+        caller must use allreduce_images_host (and say so in what it reports)."""
         from . import hip_api
-        uid = ctx.comm_unique_id() if self.rank == 0 else b''
+        ok, uid = 1.0, bytes(hip_api.NXC_UNIQUE_ID_BYTES)
+        if self.rank == 0:
+            try:
+                uid = ctx.comm_unique_id()
+            except hip_api.HipError as err:
+                print(f'[nexoclom_amd] RCCL unavailable: {err}')
+                ok = 0.0
         uid = self.bcast_bytes(uid, hip_api.NXC_UNIQUE_ID_BYTES)
-        ctx.comm_init(uid, self.rank, self.world)
+        if self.reduce(ok, 'MIN') < 1.0:
+            return False
+        try:
+            ctx.comm_init(uid, self.rank, self.world)
+        except hip_api.HipError as err:
+            print(f'[nexoclom_amd] rank {self.rank}: RCCL communicator failed: {err}')
+            ok = 0.0
+        return self.reduce(ok, 'MIN') >= 1.0
 
     def close(self):
         if self.dist and self.dist.is_initialized():

@@ -306,3 +306,25 @@ def test_reemission_statistics_follow_the_reference_process(ctx):
     e_in = 0.5*np.sum(X0[:, 4:7]**2, axis=1) + GM/r_in
     e_out = 0.5*speed**2 + GM/1.0
     assert np.allclose(e_out, e_in, rtol=2e-3)           # one RK step of free fall in between
+
+
+def test_output_files_round_trip(ctx, tmp_path):
+    """f-3: the on-disk Output (columnar float32 .npz instead of the reference's pickle): what
+    restore() gives back is what save() stored (compress filter + 32-bit down-cast,
+    Output.py:522-570), and ModelImage built from the files equals the in-memory one."""
+    inputs = Input(os.path.join(PKG_INPUTS, 'Ca.isotropic.flat.input'), savepath=str(tmp_path))
+    inputs.run(1200, packs_per_it=600, seed=3, context=ctx)
+    ids, files, npack, total = inputs.search()
+    assert len(files) == 2 and all(os.path.exists(f) for f in files) and npack == 1200
+    params = {'quantity': 'column', 'dims': '48,48', 'width': '6,6'}
+    mem = inputs.produce_image(params, context=ctx)
+    image = np.zeros((48, 48)); counts = np.zeros((48, 48))
+    for f, out in zip(files, inputs._catalogue):
+        back = Output.restore(f)
+        assert back.X.x.dtype == np.float64 and len(back.X) == len(out.X)
+        assert np.array_equal(back.X.x.values, out.X.x.values.astype(np.float64))
+        assert back.totalsource == out.totalsource and back.nsteps == out.nsteps
+        im, ct = mem.create_image(f)
+        image += im.histogram; counts += ct.histogram
+    assert np.array_equal(counts, mem.packet_image)
+    np.testing.assert_allclose(image*mem.atoms_per_packet, mem.image, rtol=1e-12)
