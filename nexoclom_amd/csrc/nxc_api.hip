@@ -88,7 +88,8 @@ struct PackedLut {
     std::vector<unsigned char> bytes;
 };
 
-int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, const char *what)
+int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, const char *what,
+             int cells_per_node = 4)
 {
     if (n < 2 || n > 65000 || !xp || !fp)
         return fail(NXC_ERR_ARG, std::string(what) + ": table needs 2..65000 points");
@@ -96,7 +97,7 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
         if (!(xp[j + 1] > xp[j]))
             return fail(NXC_ERR_ARG, std::string(what) + ": abscissae must be strictly ascending");
     int ncell = 64;
-    while (ncell < 4 * n && ncell < 16384) ncell <<= 1;
+    while (ncell < cells_per_node * n && ncell < 16384) ncell <<= 1;
     const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 31) & ~size_t(31);
     out.bytes.assign((size_t)n * 32 + cell_bytes, 0);
     double *rec = reinterpret_cast<double *>(out.bytes.data());
@@ -171,6 +172,8 @@ struct nxc_handle {
     ForceK F{};
     ImageK G{};
     PackedLut force_lut;
+    std::vector<double> force_v, force_a;        // raw table (re-packed with fewer cells if LDS is short)
+    int force_cells_per_node = 16;
     std::vector<unsigned char> image_part;       // lines, then xedges, zedges
     LdsHeader header{};                          // host copy of the blob's first bytes
     LutDesc line_local[NXC_MAX_LINES]{};
@@ -221,11 +224,21 @@ int ensure(void **ptr, size_t *cap, size_t bytes)
 int upload_blob(nxc_handle *h)
 {
     const size_t hb = NXC_HEADER_BYTES;
-    const size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
     const size_t ib = h->have_image ? h->image_part.size() : 0;
+    const size_t limit = 160 * 1024 - 32 - (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
+    size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
+    while (h->have_forces && hb + fb + ib > limit && h->force_cells_per_node > 2) {
+        h->force_cells_per_node /= 2;          // trade lookup hit rate for LDS space
+        PackedLut lut;
+        int rc2 = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
+                           "nxc_forces radiation table", h->force_cells_per_node);
+        if (rc2) return rc2;
+        h->force_lut = std::move(lut);
+        fb = h->force_lut.bytes.size();
+    }
     h->force_bytes = hb + fb;
     h->all_bytes = hb + fb + ib;
-    if (h->all_bytes + 32 + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES > 160 * 1024)
+    if (h->all_bytes > limit)
         return fail(NXC_ERR_ARG, "lookup tables exceed the 160 KiB LDS of a gfx950 CU");
     int rc = ensure(reinterpret_cast<void **>(&h->d_blob), &h->blob_cap, h->all_bytes);
     if (rc) return rc;
@@ -460,10 +473,21 @@ int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
     PackedLut lut;
     const double zero_one[2] = {0.0, 1.0}, zeros[2] = {0.0, 0.0};
     int rc;
-    if (f->radpres)
-        rc = pack_lut(f->v_tab, f->a_tab, f->n_tab, lut, "nxc_forces radiation table");
-    else
-        rc = pack_lut(zero_one, zeros, 2, lut, "placeholder table");
+    if (f->radpres) {
+        if (f->n_tab < 2 || !f->v_tab || !f->a_tab) return fail(NXC_ERR_ARG, "radiation table missing");
+        h->force_v.assign(f->v_tab, f->v_tab + f->n_tab);
+        h->force_a.assign(f->a_tab, f->a_tab + f->n_tab);
+    } else {
+        h->force_v.assign(zero_one, zero_one + 2);
+        h->force_a.assign(zeros, zeros + 2);
+    }
+    // 8 cells per node: a cell then rarely holds two nodes (0.5 % of the Na table's cells against
+    // 2 % at 4), so the two-row probe of lut_interp hits and the divergent walk mostly stays out
+    // of the step loop; 16 measured slower again in the image kernel (LDS footprint).
+    h->force_cells_per_node = 8;
+    if (const char *e = std::getenv("NXC_FORCE_CELLS")) h->force_cells_per_node = std::max(2, std::atoi(e));
+    rc = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
+                  "nxc_forces radiation table", h->force_cells_per_node);
     if (rc) return rc;
     h->force_lut = std::move(lut);
     h->F.GM = f->GM;
