@@ -500,13 +500,42 @@ NXC_DEV int bin_index(double v, int edges, int n, double lo, double hi, double i
 
 NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 
-// Adds one sample to the image pair.  Returns 1 if the sample fell inside the image.
-// The fp64 add is the hardware global_atomic_add_f64; counts are 64-bit integer atomics.
-// Samples outside the image skip the weight (only its finiteness assert is kept: the weight is
-// finite iff frac and the radial velocity are).
+// Per-lane pending contribution to one pixel.  Consecutive records of a packet often fall into
+// the same pixel (a 30 s step moves a packet by about one pixel of a 512^2 image), so a lane
+// keeps summing weight and count while the pixel does not change and only then issues the two
+// global atomics (the hardware global_atomic_add_f64 and a 64-bit integer add).  The fused kernel
+// is bound by the chip's scattered-atomic rate, so every merged pair is time saved; the packet
+// counts stay exact and the weighted sum only changes its (already arbitrary) summation order.
+struct PixelAcc {
+    long long pix = -1;
+    double w = 0.0;
+    unsigned long long c = 0;
+
+    NXC_DEV void flush(double *image, unsigned long long *counts, int dbg)
+    {
+        if (pix >= 0 && dbg != 1) {
+            if (w != 0.0 && dbg != 3) unsafeAtomicAdd(&image[pix], w);
+            if (dbg != 2) atomicAdd(&counts[pix], c);
+        }
+        pix = -1; w = 0.0; c = 0;
+    }
+    NXC_DEV void add(long long p, double wt, double *image, unsigned long long *counts, int dbg)
+    {
+        if (p != pix) {
+            flush(image, counts, dbg);
+            pix = p;
+        }
+        w += wt;
+        c += 1;
+    }
+};
+
+// Weighs one sample and hands it to the lane's pixel accumulator.  Returns 1 if the sample fell
+// inside the image.  Samples outside the image skip the weight (only its finiteness assert is
+// kept: the weight is finite iff frac and the radial velocity are).
 NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y, double z,
                          double vy, double frac, double *image, unsigned long long *counts,
-                         unsigned long long &nonfinite)
+                         unsigned long long &nonfinite, PixelAcc &acc)
 {
     if (R.downcast) {
         x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
@@ -538,9 +567,6 @@ NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y
     }
     w = nxc_div_const(w, R.apix, R.rs_apix);                       // ModelImage.py:262
     if (!(__builtin_fabs(w) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;   // :170
-    const int64_t pix = (int64_t)ix * R.nz + iz;
-    if (R.dbg == 1) return 1;
-    if (w != 0.0 && R.dbg != 3) unsafeAtomicAdd(&image[pix], w);
-    if (R.dbg != 2) atomicAdd(&counts[pix], 1ull);
+    acc.add((long long)ix * R.nz + iz, w, image, counts, R.dbg);
     return 1;
 }

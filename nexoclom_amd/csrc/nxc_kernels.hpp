@@ -117,6 +117,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
+    PixelAcc acc;
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -129,7 +130,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         if (IMAGE && alive) {
             my_samples++;
             my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                      my_nonfinite);
+                                      my_nonfinite, acc);
         }
         long long k = 0;
         int nbounce = 0;
@@ -145,7 +146,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
             if (IMAGE && alive) {
                 my_samples++;
                 my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                          my_nonfinite);
+                                          my_nonfinite, acc);
             }
         }
         if (final_out) {
@@ -154,6 +155,7 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         }
         if (steps_out) steps_out[i] = k;
     }
+    if (IMAGE) acc.flush(image, counts, IR.dbg);
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -241,6 +243,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
+    PixelAcc acc;
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     WaveQueue q;
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
@@ -255,7 +258,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             if (IMAGE && s[7] > 0.0) {
                 my_samples++;
                 my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                          my_nonfinite);
+                                          my_nonfinite, acc);
             }
         }
         if (__ballot(has) == 0) break;
@@ -269,7 +272,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                     if (IMAGE) {
                         my_samples++;
                         my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image,
-                                                  counts, my_nonfinite);
+                                                  counts, my_nonfinite, acc);
                     }
                     done = k >= n_iter;
                 } else {
@@ -286,6 +289,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             }
         }
     }
+    if (IMAGE) acc.flush(image, counts, IR.dbg);
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -387,13 +391,15 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 {
     stage_tables(blob, stage_bytes);
     const ImageRegs IR = image_regs(lds_header().G);
+    PixelAcc acc;
     unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p;
          i += (int64_t)gridDim.x * blockDim.x) {
         my_samples++;
         my_binned += image_sample(lds_header().G, IR, x[i], y[i], z[i], vy[i], frac[i], image, counts,
-                                  my_nonfinite);
+                                  my_nonfinite, acc);
     }
+    acc.flush(image, counts, IR.dbg);
     flush_counter(&ctr->samples, my_samples);
     flush_counter(&ctr->samples_binned, my_binned);
     flush_counter(&ctr->nonfinite, my_nonfinite);
