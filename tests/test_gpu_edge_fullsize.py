@@ -1,0 +1,137 @@
+"""Edge cases and full-size (BASELINE configs[1]: 1e6 packets) property checks on the GPU."""
+import numpy as np
+import pytest
+
+from nexoclom_amd import hip_api
+from oracle import np_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, dims=(64, 64), quantity='radiance'):
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    im = H.image_setup(f, quantity, dims=dims)
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], quantity, im['xedges'], im['zedges'],
+                  im['g_tables'])
+    return f, im
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 767, 769])
+def test_ragged_packet_counts(ctx, coracle, n):
+    """Packet counts around the wave (64) and workgroup (768) sizes, through both kernels."""
+    f, im = _setup(ctx)
+    X0 = H.sample_x0(n, 100 + n, 6000.)
+    nsteps, n_iter = O.n_output_steps(6000., 30.)
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., n_iter, 25., image=True, want_final=True, want_steps=True)
+    image, counts = ctx.image_download()
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                              im['xedges'], im['zedges'])
+    c = coracle.integrate_const(f, X0, 30., n_iter, 25., img=desc)
+    assert np.array_equal(g['final'], c['final']) and np.array_equal(g['steps'], c['steps'])
+    assert np.array_equal(counts, c['counts'])
+    t = ctx.integrate_const(30., n_iter, 25., nrec=nsteps, want_final=True)
+    assert np.array_equal(t['final'], c['final'])
+
+
+def test_dead_on_arrival_and_zero_iterations(ctx, coracle):
+    f, im = _setup(ctx)
+    X0 = H.sample_x0(300, 5, 3000.)
+    X0[::3, 7] = 0.0                       # frac = 0: never stepped (Output.py:382)
+    X0[1::3, 1:4] *= 30.0                  # already beyond outeredge: dies at its first test
+    nsteps, n_iter = O.n_output_steps(3000., 30.)
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., n_iter, 25., image=True, want_final=True, want_steps=True)
+    c = coracle.integrate_const(f, X0, 30., n_iter, 25.)
+    assert np.array_equal(g['steps'], c['steps']) and np.all(g['steps'][::3] == 0)
+    assert np.all(g['steps'][1::3] == 1)
+    assert np.array_equal(g['final'], c['final'])
+    ctx.image_clear()
+    g0 = ctx.integrate_const(30., 0, 25., image=True, want_final=True, want_steps=True)
+    assert np.all(g0['steps'] == 0) and np.array_equal(g0['final'], X0)
+    _, counts = ctx.image_download()
+    assert counts.sum() <= (X0[:, 7] > 0).sum()      # only the initial records were offered
+
+
+def test_empty_and_single_inputs(ctx):
+    f, im = _setup(ctx)
+    ctx.image_clear()
+    ctx.image_accumulate(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0))
+    image, counts = ctx.image_download()
+    assert counts.sum() == 0 and image.sum() == 0
+    a, i = ctx.state(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0))
+    assert a.shape == (0, 3) and i.shape == (0,)
+    r, d = ctx.rk5_step(np.zeros((0, 8)), 30.0, want_delta=True)
+    assert r.shape == (0, 8)
+    with pytest.raises(hip_api.HipError):
+        ctx.upload_packets(np.zeros((0, 8)))
+        ctx.integrate_const(30., 10, 25.)           # no resident packets -> loud error
+
+
+def test_reference_default_image_size_fits_lds(ctx, coracle):
+    """dims 800 x 800 is ModelImage's default (ModelImage.py:53): the tables must still fit the
+    160 KB LDS (the force-table cell index shrinks to make room)."""
+    f, im = _setup(ctx, dims=(800, 800))
+    X0 = H.sample_x0(3000, 8, 50000.)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    ctx.upload_packets(X0)
+    ctx.integrate_const(30., n_iter, 25., image=True)
+    image, counts = ctx.image_download()
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                              im['xedges'], im['zedges'])
+    c = coracle.integrate_const(f, X0, 30., n_iter, 25., img=desc, threads=4)
+    assert np.array_equal(counts, c['counts'])
+    np.testing.assert_allclose(image, c['image'], rtol=1e-11)
+
+
+def test_full_size_properties_1e6_packets(ctx):
+    """BASELINE configs[1] size.  Size-independent properties: counters are consistent, the image
+    is additive over packet shards (what the multi-GPU reduce relies on), and integrating with or
+    without the image gives the same work."""
+    f, im = _setup(ctx, dims=(512, 512))
+    n = 1_000_000
+    X0 = H.sample_x0(n, 1234, 50000.)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., n_iter, 25., image=True, want_steps=True)
+    ctr = ctx.counters()
+    image, counts = ctx.image_download()
+    assert ctr['particle_steps'] == int(g['steps'].sum())
+    assert ctr['samples_binned'] == int(counts.sum())
+    assert ctr['samples'] >= ctr['samples_binned'] and ctr['nonfinite'] == 0
+    assert 100 < g['steps'].mean() < 160 and g['steps'].max() <= n_iter
+    ctx.integrate_const(30., n_iter, 25., image=False)
+    assert ctx.counters()['particle_steps'] == ctr['particle_steps']
+    # shard additivity: two halves accumulated one after the other == the whole
+    ctx.image_clear()
+    for part in (X0[:n//2], X0[n//2:]):
+        ctx.upload_packets(part)
+        ctx.integrate_const(30., n_iter, 25., image=True)
+    image2, counts2 = ctx.image_download()
+    assert np.array_equal(counts, counts2)
+    np.testing.assert_allclose(image2, image, rtol=1e-10, atol=0)
+    # symmetry of the physics: seen from over the pole the cloud is statistically symmetric
+    # dawn/dusk (image x), while the anti-sunward tail makes it asymmetric along the other axis
+    dusk, dawn = float(counts[256:, :].sum()), float(counts[:256, :].sum())
+    assert abs(dusk - dawn)/(dusk + dawn) < 0.01
+    sunward, tail = float(counts[:, :256].sum()), float(counts[:, 256:].sum())
+    assert abs(sunward - tail)/(sunward + tail) > 0.2
+
+
+def test_gravity_only_energy_at_scale(ctx):
+    """Energy conservation of the reference's test_gravity.py on 2e5 packets x 667 steps."""
+    f = H.mercury_forces('Na', 3.14, True, False, 0.0)
+    f.photo = None
+    H.set_ctx_forces(ctx, f)
+    n = 200_000
+    X0 = H.sample_x0(n, 77, 20000., vprob=4., delv=4.)
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., 667, 1e30, want_final=True, want_steps=True)
+    fin = g['final']
+    alive = fin[:, 7] > 0
+    assert alive.sum() > 1000
+    e0 = 0.5*np.sum(X0[:, 4:7]**2, axis=1) + f.GM/np.linalg.norm(X0[:, 1:4], axis=1)
+    e1 = 0.5*np.sum(fin[:, 4:7]**2, axis=1) + f.GM/np.linalg.norm(fin[:, 1:4], axis=1)
+    assert np.allclose(e1[alive], e0[alive], rtol=1e-6, atol=1e-14)
