@@ -138,3 +138,50 @@ def test_rotation_golden():
         assert np.allclose(M @ M.T, np.eye(3), atol=1e-14)
     assert np.array_equal(rotation_matrix(0.3, np.array([0., 0., 2.])),
                           O.rotation_matrix(0.3, np.array([0., 0., 2.])))
+
+
+def test_los_oracle_equals_brute_force():
+    """The KD-tree restatement of compute_iteration (np_oracle.los_iteration) against an
+    independent brute-force evaluation of the same selection rule (cone, planet cut-off, union of
+    the pre-selection balls): pins the oracle the GPU LOS kernel is checked with."""
+    from tests.test_gpu_api import _orbit
+    rng = np.random.default_rng(12)
+    f = H.mercury_forces('Na', 1.3)
+    P = 20000
+    d = rng.normal(size=(P, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    pts = d*rng.uniform(1.0, 6.0, P)[:, None]
+    smp = dict(x=pts[:, 0], y=pts[:, 1], z=pts[:, 2], vy=rng.normal(size=P)*1e-3,
+               frac=rng.uniform(0.01, 1, P), Index=np.arange(P) % 500)
+    pos, look = _orbit(40, seed=1)
+    sc = dict(x=pos[:, 0], y=pos[:, 1], z=pos[:, 2], xbore=look[:, 0], ybore=look[:, 1],
+              zbore=look[:, 2])
+    dphi = np.radians(4.0)
+    gt = H.g_tables('Na', f.aplanet, f.R_km, (5891, 5897))
+    rad, npk, inc, used = O.los_iteration(smp, sc, dphi, 25., f.vrplanet, gt, f.R_km*1e5,
+                                          n_index=500)
+    dist_plan, ladders = O.los_geometry(sc, 25., dphi)
+    for i in range(40):
+        x_sc, bore = pos[i], look[i]
+        rel = pts - x_sc
+        dist = np.linalg.norm(rel, axis=1)
+        losrad = rel @ bore
+        with np.errstate(invalid='ignore'):
+            ang = np.arccos(np.minimum(losrad/dist, 1))
+        cone = (losrad < dist_plan[i]) & (ang <= dphi)
+        t = ladders[i]
+        centres = x_sc[None, :] + bore[None, :]*t[:, None]
+        ball = np.zeros(P, bool)
+        for k in range(len(t)):
+            ball |= np.sum((pts - centres[k])**2, axis=1) <= (t[k]*np.sin(2*dphi))**2
+        sel = cone & ball
+        assert npk[i] == sel.sum()
+        assert np.array_equal(np.sort(used[i]), np.nonzero(sel & (_w(smp, sel, i, x_sc, bore, losrad, dist, f, gt, dphi) > 0))[0])
+    assert npk.sum() > 100
+
+
+def _w(smp, sel, i, x_sc, bore, losrad, dist, f, gt, dphi):
+    w = O.packet_weights(smp['frac'], smp['vy'] + f.vrplanet, 1., 'radiance', gt)
+    apix = np.pi*(dist*np.sin(dphi))**2*(f.R_km*1e5)**2
+    hit = x_sc[None, :] + bore[None, :]*losrad[:, None]
+    oos = (np.linalg.norm(hit[:, [0, 2]], axis=1) > 1) | (hit[:, 1] < 0)
+    return np.where(sel, w/apix*oos, 0.0)
