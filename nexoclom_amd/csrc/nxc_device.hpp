@@ -449,6 +449,17 @@ NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int
 // Image: data_simulation/ModelImage.py:242-269, ModelResult.py:140-170, math/histogram.py:32-36
 // ---------------------------------------------------------------------------------------------
 
+// Values read from LDS are wave-uniform but land in vector registers; readfirstlane moves them
+// to scalar registers so that they do not add to the VGPR pressure of the step loop.
+NXC_DEV double wave_uniform(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+NXC_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // Launch constants of the image path that are worth a register: read from the LDS header once
 // per thread before the step loop (the compiler cannot hoist LDS loads over the loop's LDS
 // stores).  The two refined reciprocals serve the per-sample divisions by 1e6 and by Apix.
@@ -457,6 +468,16 @@ struct ImageRegs {
     double x_lo, x_hi, x_inv_step, z_lo, z_hi, z_inv_step;
     int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg;
 };
+
+NXC_DEV LutView uniform_view(const LutDesc &d)
+{
+    LutView v = lut_view(d);
+    v.rec = wave_uniform(v.rec); v.fs = wave_uniform(v.fs); v.cell = wave_uniform(v.cell);
+    v.n = wave_uniform(v.n); v.ncell = wave_uniform(v.ncell);
+    v.x0 = wave_uniform(v.x0); v.xlast = wave_uniform(v.xlast); v.inv_w = wave_uniform(v.inv_w);
+    v.f_first = 0.0; v.f_last = 0.0;
+    return v;
+}
 
 NXC_DEV ImageRegs image_regs(const ImageK &G)
 {
@@ -471,6 +492,15 @@ NXC_DEV ImageRegs image_regs(const ImageK &G)
     R.z_lo = lds_f64(R.zedges); R.z_hi = lds_f64(R.zedges + 8 * R.nz);
     R.x_inv_step = G.x_inv_step; R.z_inv_step = G.z_inv_step;
     R.quantity = G.quantity; R.n_lines = G.n_lines; R.downcast = G.downcast_f32; R.dbg = G.dbg;
+    R.vrplanet = wave_uniform(R.vrplanet); R.apix = wave_uniform(R.apix);
+    R.rs_1e6 = wave_uniform(R.rs_1e6); R.rs_apix = wave_uniform(R.rs_apix);
+    R.x_lo = wave_uniform(R.x_lo); R.x_hi = wave_uniform(R.x_hi);
+    R.z_lo = wave_uniform(R.z_lo); R.z_hi = wave_uniform(R.z_hi);
+    R.x_inv_step = wave_uniform(R.x_inv_step); R.z_inv_step = wave_uniform(R.z_inv_step);
+    R.xedges = wave_uniform(R.xedges); R.zedges = wave_uniform(R.zedges);
+    R.nx = wave_uniform(R.nx); R.nz = wave_uniform(R.nz);
+    R.quantity = wave_uniform(R.quantity); R.n_lines = wave_uniform(R.n_lines);
+    R.downcast = wave_uniform(R.downcast); R.dbg = wave_uniform(R.dbg);
     return R;
 }
 
