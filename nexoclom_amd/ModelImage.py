@@ -123,7 +123,7 @@ class ModelResult:
 class ModelImage(ModelResult):
     def __init__(self, inputs, params, overwrite=False, distribute=None, *, npackets=None,
                  seed=None, packs_per_it=None, downcast=True, device=0, context=None,
-                 sampler='numpy'):
+                 sampler='numpy', first_index=0, finalize=True):
         super().__init__(inputs, params)
         self.type = 'image'
         self.origin = self.params.get('origin', inputs.geometry.planet)
@@ -161,7 +161,7 @@ class ModelImage(ModelResult):
         self.counters = {}
 
         if npackets is not None:
-            self._stream(int(npackets), seed, packs_per_it, downcast, sampler)
+            self._stream(int(npackets), seed, packs_per_it, downcast, sampler, first_index)
         else:
             outputs = [o for o in inputs._catalogue]
             if not outputs:
@@ -175,7 +175,13 @@ class ModelImage(ModelResult):
                 self.xaxis = image.x
                 self.zaxis = image.y
 
-        mod_rate = self.totalsource / inputs.options.endtime.value      # ModelImage.py:102-105
+        if finalize:
+            self.finalize()
+
+    def finalize(self):
+        """Scale to a source rate of 1e23 atoms/s (ModelImage.py:102-105); deferred by the
+        multi-GPU path until the shards are summed."""
+        mod_rate = self.totalsource / self.inputs.options.endtime.value
         self.atoms_per_packet = 1e23 / mod_rate if mod_rate > 0 else 0.
         self.sourcerate = Quantity(1., '1e23/s')
         self.image *= self.atoms_per_packet
@@ -222,7 +228,7 @@ class ModelImage(ModelResult):
         return (Histogram2dResult(image, self.xedges, self.zedges),
                 Histogram2dResult(counts.astype(float), self.xedges, self.zedges))
 
-    def _stream(self, npackets, seed, packs_per_it, downcast, sampler='numpy'):
+    def _stream(self, npackets, seed, packs_per_it, downcast, sampler='numpy', first_index=0):
         """Fused integrate + image over ``npackets`` packets, chunked like Input.run."""
         from .Output import Output, n_output_steps
         inputs = self.inputs
@@ -239,7 +245,8 @@ class ModelImage(ModelResult):
             n = min(chunk, npackets - done)
             if sampler == 'device':      # one counter space: chunk k continues at packet `done`
                 out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
-                             sampler='device', first_index=done, materialize_x0=False)
+                             sampler='device', first_index=first_index + done,
+                             materialize_x0=False)
             else:
                 out = Output(inputs, n, seed=None if seed is None else seed + k,
                              integrate=False, save=False, context=ctx)
@@ -249,7 +256,7 @@ class ModelImage(ModelResult):
                 first = False
             out.upload(ctx)
             ctx.set_bounce(out._bounce)
-            ctx.set_first_index(done)
+            ctx.set_first_index(first_index + done)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():
                 totals[key] = totals.get(key, 0) + v

@@ -99,3 +99,36 @@ class ControlPlane:
         if self.dist and self.dist.is_initialized():
             self.dist.destroy_process_group()
             self.dist = None
+
+
+def sharded_image(inputs, params, npackets, seed, cp=None, device=None, downcast=True,
+                  sampler='device', packs_per_it=None):
+    """Multi-GPU ModelImage: every rank integrates and bins its contiguous shard of the global
+    packet index range, then the image pairs are summed over RCCL (ModelImage.py:96-98 across
+    GPUs).  With the counter-based device sampler, packet i is the same packet whatever the
+    number of ranks, so the packet-count image is identical for 1, 2, 4 or 8 GPUs.
+
+    Launch one process per GPU (torchrun); returns a ModelImage holding the global image on
+    every rank."""
+    from . import hip_api
+    from .ModelImage import ModelImage
+    cp = cp or ControlPlane()
+    ndev = hip_api.device_count()
+    ctx = hip_api.Context((cp.local_rank if device is None else device) % max(ndev, 1))
+    lo, hi = shard_range(int(npackets), cp.rank, cp.world)
+    img = ModelImage(inputs, params, npackets=hi - lo, seed=seed, context=ctx, downcast=downcast,
+                     sampler=sampler, packs_per_it=packs_per_it, first_index=lo,
+                     finalize=False)
+    if cp.world > 1:
+        if cp.init_rccl(ctx):
+            ctx.image_allreduce()
+            image, counts = ctx.image_download()
+            ctx.comm_destroy()
+        else:
+            image, counts = cp.allreduce_images_host(*ctx.image_download())
+        img.image = image
+        img.packet_image = counts.astype(float)
+        img.totalsource = cp.reduce(img.totalsource, 'SUM')
+        img.npackets = int(cp.reduce(img.npackets, 'SUM'))
+    img.finalize()
+    return img

@@ -328,3 +328,22 @@ def test_output_files_round_trip(ctx, tmp_path):
         image += im.histogram; counts += ct.histogram
     assert np.array_equal(counts, mem.packet_image)
     np.testing.assert_allclose(image*mem.atoms_per_packet, mem.image, rtol=1e-12)
+
+
+def test_sharded_image_is_independent_of_the_shard_count(ctx):
+    """Multi-GPU semantics on one GPU: the image of N device-sampled packets equals the sum of
+    the images of its index shards (what nexoclom_amd.distributed.sharded_image reduces over
+    RCCL), packet counts exactly -- i.e. 1, 2 or 8 GPUs give the same image."""
+    from nexoclom_amd.distributed import ControlPlane, shard_range, sharded_image
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    params = {'quantity': 'radiance', 'dims': '128,128'}
+    whole = sharded_image(inputs, params, 9001, seed=42, cp=ControlPlane(world=1, rank=0), device=0)
+    image = np.zeros((128, 128)); counts = np.zeros((128, 128)); total = 0.
+    for rank in range(3):
+        lo, hi = shard_range(9001, rank, 3)
+        part = ModelImage(inputs, params, npackets=hi - lo, seed=42, context=ctx,
+                          sampler='device', first_index=lo, finalize=False)
+        image += part.image; counts += part.packet_image; total += part.totalsource
+    assert total == whole.totalsource == 9001*1668
+    assert np.array_equal(counts, whole.packet_image)
+    np.testing.assert_allclose(image*whole.atoms_per_packet, whole.image, rtol=1e-11)
