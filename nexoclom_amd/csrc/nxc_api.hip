@@ -329,12 +329,12 @@ size_t persist_lds(size_t table_bytes)
     return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
 }
 
-template <bool IMAGE, bool BOUNCE>
+template <bool IMAGE, bool BOUNCE, bool FULL = false>
 int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
                  double *d_final, long long *d_steps)
 {
     int grid = 1, rc;
-    auto kernel = k_const_fused<IMAGE, BOUNCE>;
+    auto kernel = k_const_fused<IMAGE, BOUNCE, FULL>;
     if ((rc = prep_kernel(kernel, lds))) return rc;
     if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, h->n_packets, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
@@ -356,6 +356,11 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
     if ((rc = upload_step(h, step))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     const double edge2 = sqrt_threshold(outeredge);
+    // gravity + radiation pressure + photo-loss, no re-emission: the compile-time specialisation
+    const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO && !h->have_bounce;
+    if (full)
+        return image ? launch_fused<true, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
+                     : launch_fused<false, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps);
     if (image)
         return h->have_bounce ? launch_fused<true, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
                               : launch_fused<true, false>(h, tables, lds, n_iter, edge2, d_final, d_steps);

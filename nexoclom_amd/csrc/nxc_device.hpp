@@ -124,11 +124,15 @@ NXC_DEV bool sunlit(double x, double y, double z)
     return (s > 0x1.0000000000001p+0) || (y < 0.0);
 }
 
+// FULL = gravity + radiation pressure + photo-loss known at compile time (the common run): the
+// wave-uniform switches disappear and the force evaluation becomes one basic block, which lets
+// the scheduler overlap the table's LDS round trips with the gravity arithmetic.
+template <bool FULL>
 NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, double z, double vy,
                         double &ax, double &ay, double &az, double &ion)
 {
     double gx = 0.0, gy = 0.0, gz = 0.0;
-    if (F.grav) {                                         // state.py:19-21
+    if (FULL || F.grav) {                                 // state.py:19-21
         const double s2 = (x * x + y * y) + z * z;
         const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
         if (s2 > 0x1p-130 && s2 < 0x1p+130) {
@@ -146,7 +150,7 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
     }
     const bool lit = sunlit(x, y, z);
     double ry = 0.0;
-    if (F.rad) {                                          // state.py:27-36
+    if (FULL || F.rad) {                                  // state.py:27-36
         const double vv = vy + F.vrplanet;
         // interp * out_of_shadow: the product with False is a zero whose sign cannot matter in
         // gy + ry
@@ -156,7 +160,8 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
     ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
     ay = gy + ry;
     az = gz;
-    if (F.loss == LOSS_LIFETIME) ion = F.inv_lifetime;    // state.py:44-46
+    if (FULL) ion = lit ? F.photo : 0.0;
+    else if (F.loss == LOSS_LIFETIME) ion = F.inv_lifetime;    // state.py:44-46
     else if (F.loss == LOSS_PHOTO) ion = lit ? F.photo : 0.0;   // state.py:48-52 (photo * bool)
     else ion = 0.0;
 }
@@ -190,7 +195,7 @@ struct StepW {
 // error estimate |h * sum_{i<6} (B5-B4)_i k_i| (rk5.py:38-46; the 7th stage is left out there).
 // Each stage is accumulated from zero in the order i = 0..n with terms (h*a)*k and the initial
 // state added last (rk5.py:32-36); frac is carried as log(frac) (rk5.py:25,35,50).
-template <bool DELTA, bool UNIFORM_H>
+template <bool DELTA, bool UNIFORM_H, bool FULL = false>
 NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double h,
                       const StepW &W, double (&d)[8])
 {
@@ -202,7 +207,7 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
 #pragma unroll
     for (int n = 0; n < 6; n++) {
         kv[n][0] = vx; kv[n][1] = vy; kv[n][2] = vz;
-        state_eval(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
+        state_eval<FULL>(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
         // The reference starts each sum from 0.0 (0 + t0): dropped, it can only change the sign
         // of an exactly-zero sum.
         double nx, ny, nz, nvx, nvy, nvz, nlf;

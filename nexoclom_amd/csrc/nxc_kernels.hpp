@@ -73,7 +73,7 @@ k_state(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, i
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         double a0, a1, a2, l;
-        state_eval(F, T, x[i], y[i], z[i], vy[i], a0, a1, a2, l);
+        state_eval<false>(F, T, x[i], y[i], z[i], vy[i], a0, a1, a2, l);
         ax[i] = a0; ay[i] = a1; az[i] = a2; ion[i] = l;
     }
 }
@@ -230,7 +230,7 @@ struct WaveQueue {
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
-template <bool IMAGE, bool BOUNCE>
+template <bool IMAGE, bool BOUNCE, bool FULL>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
@@ -265,7 +265,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         if (has) {
             bool done = !(s[7] > 0.0) || k >= n_iter;
             if (!done) {
-                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
+                rk5_step<false, true, FULL>(F, T, s, 0.0, lds_header().W, d);
                 apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
                 k++; my_steps++;
                 if (s[7] > 0.0) {
