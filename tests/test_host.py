@@ -179,3 +179,115 @@ def test_surface_interaction_tables():
     assert cfg['temp_dependent'] == 1 and cfg['accomfactor'] == 0.2 and len(cfg['tx']) == 205
     inp2 = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
     assert bounce_config(inp2, -1.5e-6, 2440.53, 7) is None
+
+
+def _write(tmp_path, text):
+    p = tmp_path / 'case.input'
+    p.write_text(text)
+    return str(p)
+
+
+BASE = ('SpatialDist.type = uniform\nSpeedDist.type = flat\nSpeedDist.vprob = 4.\n'
+        'SpeedDist.delv = 4.\noptions.endtime = 10800.\noptions.species = Na\n')
+
+
+def test_parser_geometry_variants(tmp_path):
+    """The geometry cases of the reference's tests/test_data/inputfiles/Geometry.0[1-3].input and
+    test_input_classes.py: planet with moons, start point, objects, phi, subsolarpoint, starttime."""
+    inp = Input(_write(tmp_path, 'geometry.planet = Jupiter\ngeometry.StartPoint = Io\n'
+                                 'geometry.objects = Jupiter, Io, Europa\ngeometry.phi = 1., 2.\n'
+                                 'geometry.subsolarpoint = 3.14, 0\ngeometry.taa = 1.57\n' + BASE))
+    g = inp.geometry
+    assert g.planet.object == 'Jupiter' and g.startpoint == 'Io'
+    assert {o.object for o in g.objects} == {'Jupiter', 'Io', 'Europa'}
+    assert g.phi == (1., 2.) and g.subsolarpoint == (3.14, 0.) and g.taa == 1.57
+    assert g.type == 'geometry without starttime'
+    with pytest.raises(InputError):                      # wrong number of orbital positions
+        Input(_write(tmp_path, 'geometry.planet = Jupiter\ngeometry.startpoint = Io\n'
+                               'geometry.objects = Jupiter, Io, Europa\ngeometry.phi = 1.\n' + BASE))
+    with pytest.raises(InputError):                      # moons but no phi
+        Input(_write(tmp_path, 'geometry.planet = Jupiter\ngeometry.startpoint = Io\n' + BASE))
+    with pytest.raises(ValueError):                      # start point not in the system
+        Input(_write(tmp_path, 'geometry.planet = Mercury\ngeometry.startpoint = Io\n' + BASE))
+    with pytest.raises(InputError):
+        Input(_write(tmp_path, 'geometry.planet = Jupiter\ngeometry.startpoint = Io\n'
+                               'geometry.objects = Jupiter, Moon\ngeometry.phi = 1.\n' + BASE))
+    t = Input(_write(tmp_path, 'geometry.planet = Jupiter\ngeometry.StartPoint = Io\n'
+                               'geometry.starttime = 2022-03-08T19:53:21\n' + BASE))
+    assert t.geometry.type == 'geometry with starttime'
+    assert t.geometry.time == '2022-03-08T19:53:21'
+
+
+def test_parser_surface_and_distribution_variants(tmp_path):
+    """SurfaceInteraction.0[1-6], Spatial, Speed and Angular variants of the reference's test
+    inputfiles: defaults, clamping and the required-parameter errors."""
+    geo = 'geometry.planet = Mercury\ngeometry.taa = 3.14\n'
+    s = Input(_write(tmp_path, geo + 'surfaceinteraction.stickcoef = 1.7\n' + BASE))
+    assert s.surfaceinteraction.stickcoef == 1 and s.surfaceinteraction.accomfactor is None
+    s = Input(_write(tmp_path, geo + 'surfaceinteraction.stickcoef = -0.2\n'
+                                     'surfaceinteraction.accomfactor = 0.4\n' + BASE))
+    assert s.surfaceinteraction.stickcoef == 0 and s.surfaceinteraction.accomfactor == 0.4
+    with pytest.raises(InputError):                      # partial sticking needs accomfactor
+        Input(_write(tmp_path, geo + 'surfaceinteraction.stickcoef = 0.5\n' + BASE))
+    s = Input(_write(tmp_path, geo + 'SurfaceInteraction.sticktype = temperature dependent\n'
+                                     'SurfaceInteraction.accomfactor = 0.2\n' + BASE))
+    assert s.surfaceinteraction.A == (1.57014, -0.006262, 0.1614157)
+    s = Input(_write(tmp_path, geo + 'SurfaceInteraction.sticktype = temperature dependent\n'
+                                     'SurfaceInteraction.accomfactor = 0.2\n'
+                                     'SurfaceInteraction.A = 1, -0.01, 0.2\n' + BASE))
+    assert s.surfaceinteraction.A == (1., -0.01, 0.2)
+    with pytest.raises(InputError):
+        Input(_write(tmp_path, geo + 'SurfaceInteraction.sticktype = temperature dependent\n'
+                                     'SurfaceInteraction.accomfactor = 0.2\n'
+                                     'SurfaceInteraction.A = 1, 2\n' + BASE))
+    rest = 'options.endtime = 100\noptions.atom = ca\n'
+    s = Input(_write(tmp_path, geo + 'SpatialDist.type = surface spot\nSpatialDist.longitude = 1.\n'
+                                     'SpatialDist.latitude = 0.5\nSpatialDist.sigma = 0.3\n'
+                                     'SpeedDist.type = maxwellian\nSpeedDist.temperature = 1200\n'
+                                     'AngularDist.type = 2d\nAngularDist.altitude = 0.1, 9\n' + rest))
+    assert s.spatialdist.sigma == 0.3 and s.speeddist.temperature.value == 1200.
+    assert s.angulardist.type == '2d'
+    assert [float(a) for a in s.angulardist.altitude] == [0.1, np.pi]     # clamped to pi
+    assert s.options.species == 'Ca'
+    s = Input(_write(tmp_path, geo + 'SpatialDist.type = uniform\nSpeedDist.type = sputtering\n'
+                                     'SpeedDist.alpha = 3\nSpeedDist.beta = 0.7\nSpeedDist.U = 2.\n'
+                                     'AngularDist.type = isotropic\nAngularDist.azimuth = 1, 0.5\n'
+                                     + rest))
+    assert s.speeddist.U.value == 2. and s.speeddist.alpha == 3.
+    assert [float(a) for a in s.angulardist.azimuth] == [1., 0.5]
+    with pytest.raises(InputError):
+        Input(_write(tmp_path, geo + 'SpatialDist.type = surface spot\nSpatialDist.longitude = 1.\n'
+                                     'SpeedDist.type = flat\nSpeedDist.vprob=1\nSpeedDist.delv=1\n'
+                                     + rest))
+    with pytest.raises(InputError):
+        Input(_write(tmp_path, geo + 'SpatialDist.type = nonsense\nSpeedDist.type = flat\n'
+                                     'SpeedDist.vprob=1\nSpeedDist.delv=1\n' + rest))
+
+
+def test_host_samplers_for_other_sources():
+    """maxwellian / sputtering speeds (global NumPy RNG, as the reference) and the surface spot:
+    statistical sanity of the restated samplers."""
+    import numpy.random as nprandom
+    inp = Input(os.path.join(HERE, 'inputfiles', 'Gravity.input'))
+    from nexoclom_amd.units import Quantity
+    inp.speeddist.type = 'maxwellian'
+    inp.speeddist.temperature = Quantity(1200., 'K')
+    nprandom.seed(3)
+    out = Output(inp, 50000, seed=1, integrate=False, save=False)
+    v = out.X0.v.values*out.unit_km
+    vth = np.sqrt(2*1200*1.380649e-23/(22.98976928*1.66053906660e-27))/1e3
+    assert abs(np.median(v)/vth - 1.2958) < 0.02          # median of v^3 exp(-v^2/vth^2)
+    inp.speeddist.type = 'sputtering'
+    inp.speeddist.alpha, inp.speeddist.beta, inp.speeddist.U = 3., 0.7, Quantity(2., 'eV')
+    out = Output(inp, 20000, seed=1, integrate=False, save=False)
+    v = out.X0.v.values*out.unit_km
+    assert 0.1 <= v.min() and v.max() <= 50 and 1.0 < np.median(v) < 6.0
+    inp.spatialdist.type = 'surface spot'
+    inp.spatialdist.longitude = Quantity(1.0, 'rad')
+    inp.spatialdist.latitude = Quantity(0.3, 'rad')
+    inp.spatialdist.sigma = Quantity(0.2, 'rad')
+    inp.spatialdist.exobase = 1.0
+    inp.speeddist.type = 'flat'
+    inp.speeddist.vprob, inp.speeddist.delv = Quantity(2., 'km/s'), Quantity(1., 'km/s')
+    out = Output(inp, 20000, seed=1, integrate=False, save=False)
+    assert abs(np.median(out.X0.longitude) - 1.0) < 0.05
