@@ -241,21 +241,28 @@ class ModelImage(ModelResult):
         nsteps, n_iter = n_output_steps(opt.endtime.value, float(opt.step_size))
         done, k, first = 0, 0, True
         totals = {}
+        src = bounce = None
         while done < npackets:
             n = min(chunk, npackets - done)
-            if sampler == 'device':      # one counter space: chunk k continues at packet `done`
+            if sampler == 'device' and not first:
+                # same inputs, next slice of the counter space: no need to rebuild the tables
+                ctx.sample_packets(n, 0 if seed is None else seed, first_index + done, **src)
+            elif sampler == 'device':     # one counter space: chunk k continues at packet `done`
                 out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
                              sampler='device', first_index=first_index + done,
                              materialize_x0=False)
+                src, bounce = out.source_desc(), out._bounce
             else:
                 out = Output(inputs, n, seed=None if seed is None else seed + k,
                              integrate=False, save=False, context=ctx)
+                bounce = out._bounce
             if first:
                 ctx.set_forces(**out.forces_kwargs())
                 self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
                 first = False
-            out.upload(ctx)
-            ctx.set_bounce(out._bounce)
+            if sampler != 'device':
+                out.upload(ctx)
+            ctx.set_bounce(bounce)
             ctx.set_first_index(first_index + done)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():
