@@ -137,6 +137,38 @@ typedef struct nxc_bounce_desc {
 int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d);
 int nxc_set_first_index(nxc_handle *h, int64_t first_index);  /* RNG counter of resident packet 0 */
 
+/* ---- f-4 (tail): moons and plasma-torus loss ---------------------------------------------------
+ * EXTENSION -- no reference implementation exists: particle_tracking/state.py:5-10 documents
+ * the multi-body equations of motion, :56-70 holds the commented charge-exchange stub, and
+ * Output.py:153-155 asserts 'Not set up' for planets with moons.  Parity is therefore against
+ * oracle/ only ("parity unpinned"); tests/ add physics checks (Jacobi integral, limits).
+ *   accel += sum_m gm[m] (r - r_m(t)) / |r - r_m(t)|^3
+ *   loss  += chx_k0 exp(-((rho - chx_rho0)/chx_width)^2 - (z/chx_height)^2)
+ *            [* |v - chx_omega z^ x r| / (chx_omega chx_rho0)   when chx_omega > 0]
+ *   a packet within radius[m] of moon m after a step is absorbed.
+ * Moon m moves on a circle of radius a[m] in the planet's equatorial (x, y) plane; its orbital
+ * phase is phi[m] at t_remaining = 0 (geometry.phi: 0 = superior conjunction (+y), pi/2 = over
+ * the dawn terminator (-x), docs/nexoclom/inputfiles.rst:72-77) and phi[m] - omega[m] t at
+ * t_remaining = t:  r_m = a (-sin, cos, 0).  Applies to nxc_integrate_const* only (every packet
+ * starts at t_remaining = t0); nxc_state / nxc_rk5_step / nxc_integrate_var and surface
+ * re-emission refuse to run while bodies are set.  NULL or n_moons == 0 && !chx_on clears. */
+#define NXC_MAX_MOONS 4
+typedef struct nxc_bodies_desc {
+    int32_t n_moons;
+    int32_t chx_on;
+    double gm[NXC_MAX_MOONS];      /* R^3/s^2, negative like nxc_forces.GM */
+    double radius[NXC_MAX_MOONS];  /* R */
+    double a[NXC_MAX_MOONS];       /* R */
+    double omega[NXC_MAX_MOONS];   /* rad/s */
+    double phi[NXC_MAX_MOONS];     /* rad */
+    double t0;                     /* s: t_remaining of every packet at the start of the run */
+    double chx_k0;                 /* 1/s */
+    double chx_rho0, chx_width, chx_height;   /* R */
+    double chx_omega;              /* rad/s; 0 = no dependence on the relative speed */
+} nxc_bodies_desc;
+
+int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d);
+
 /* ---- a-2: state() ---------------------------------------------------------------------------- */
 int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const double *z,
               const double *vy, double *ax, double *ay, double *az, double *ioniz);

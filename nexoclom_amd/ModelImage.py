@@ -241,7 +241,7 @@ class ModelImage(ModelResult):
         nsteps, n_iter = n_output_steps(opt.endtime.value, float(opt.step_size))
         done, k, first = 0, 0, True
         totals = {}
-        src = bounce = None
+        src = bounce = bodies = None
         while done < npackets:
             n = min(chunk, npackets - done)
             if sampler == 'device' and not first:
@@ -251,11 +251,11 @@ class ModelImage(ModelResult):
                 out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
                              sampler='device', first_index=first_index + done,
                              materialize_x0=False)
-                src, bounce = out.source_desc(), out._bounce
+                src, bounce, bodies = out.source_desc(), out._bounce, out._bodies
             else:
                 out = Output(inputs, n, seed=None if seed is None else seed + k,
                              integrate=False, save=False, context=ctx)
-                bounce = out._bounce
+                bounce, bodies = out._bounce, out._bodies
             if first:
                 ctx.set_forces(**out.forces_kwargs())
                 self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
@@ -263,6 +263,7 @@ class ModelImage(ModelResult):
             if sampler != 'device':
                 out.upload(ctx)
             ctx.set_bounce(bounce)
+            ctx.set_bodies(bodies)
             ctx.set_first_index(first_index + done)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():

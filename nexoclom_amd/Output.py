@@ -104,14 +104,17 @@ class Output:
             self.npackets = npackets
             self.totalsource = self.X0['frac'].sum()
 
-            if self.planet.moons is not None:                           # Output.py:153-155
-                assert False, 'Not set up'
-            if inputs.geometry.planet.object != inputs.geometry.startpoint:
-                assert 0, 'Not set up yet'
+            # The reference stops here for any planet with moons ('Not set up',
+            # Output.py:153-155).  EXTENSION: included moons pull on and absorb packets, a moon
+            # can be the start point, and options.chx_* adds a plasma-torus loss term
+            # (include/nexoclom_hip.h, nxc_bodies_desc).
+            self._bodies = self._bodies_config()
 
             self.sampler = sampler
             self._resident = False
             if sampler == 'device':
+                if inputs.geometry.planet.object != inputs.geometry.startpoint:
+                    raise NotImplementedError("sampler='device' launches from the planet only")
                 soa = self.context().sample_packets(
                     npackets, 0 if seed is None else seed, first_index,
                     download=materialize_x0, **self.source_desc())
@@ -131,6 +134,7 @@ class Output:
                 cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac', 'v',
                         'longitude', 'latitude', 'local_time', 'altitude', 'azimuth']
                 self.X0 = self.X0[cols]
+                self._launch_from_moon()
             else:
                 raise ValueError("sampler must be 'numpy' or 'device'")
             self.nsteps = None
@@ -214,6 +218,54 @@ class Output:
                      az0=az0, az1=az1)
         return d
 
+    def _bodies_config(self):
+        """Arguments of hip_api.Context.set_bodies, or None for the reference's single-body
+        model.  Moons are taken in the order of ``planet.moons``; geometry.phi follows it."""
+        geo, opt = self.inputs.geometry, self.inputs.options
+        included = [m for m in (self.planet.moons or []) if m in (geo.objects or ())]
+        chx = getattr(opt, 'chx', None)
+        if not included and chx is None:
+            return None
+        if opt.step_size == 0:
+            raise NotImplementedError('moons / torus loss need the constant-step driver '
+                                      '(options.step_size > 0)')
+        unit_m = self.unit_km*1e3
+        cfg = dict(moons=[], t0=float(opt.endtime.value), chx=None)
+        phis = [float(p) for p in (getattr(geo, 'phi', None) or ())]
+        assert len(phis) == len(included), 'The wrong number of orbital positions was given.'
+        for m, phi in zip(included, phis):
+            cfg['moons'].append(dict(name=m.object, gm=m.GM.value/unit_m**3,
+                                     radius=m.radius.value/self.unit_km,
+                                     a=m.a.value/self.unit_km,
+                                     omega=2*np.pi/(m.orbperiod.value*86400.), phi=phi))
+        if chx is not None:
+            omega = 2*np.pi/(self.planet.rotperiod.value*3600.) if chx['corotation'] else 0.0
+            cfg['chx'] = dict(k0=chx['k0'], rho0=chx['rho0'], width=chx['width'],
+                              height=chx['height'], omega=omega)
+        return cfg
+
+    def _launch_from_moon(self):
+        """Move packets sampled around the origin onto the start-point moon: scale to its radius,
+        rotate its local frame (-y towards the planet, -x leading) by the orbital phase at launch,
+        add its position, orbital velocity and the surface's co-rotation."""
+        geo = self.inputs.geometry
+        if geo.planet.object == geo.startpoint:
+            return
+        mo = next((m for m in self._bodies['moons'] if m['name'] == geo.startpoint), None)
+        assert mo is not None, 'geometry.startpoint must be one of geometry.objects'
+        X0 = self.X0
+        ang = mo['phi'] - mo['omega']*X0['time'].values
+        c, s_ = np.cos(ang), np.sin(ang)
+        xl, yl = X0['x'].values*mo['radius'], X0['y'].values*mo['radius']
+        xr, yr = c*xl - s_*yl, s_*xl + c*yl
+        vxl, vyl = X0['vx'].values, X0['vy'].values
+        aw = mo['a']*mo['omega']
+        X0['x'] = xr - mo['a']*s_
+        X0['y'] = yr + mo['a']*c
+        X0['z'] = X0['z'].values*mo['radius']
+        X0['vx'] = (c*vxl - s_*vyl) - aw*c - mo['omega']*yr
+        X0['vy'] = (s_*vxl + c*vyl) - aw*s_ + mo['omega']*xr
+
     def upload(self, ctx):
         """Make this Output's initial states the context's resident packet set."""
         if getattr(self, '_resident', False) and ctx is self._ctx:
@@ -243,6 +295,7 @@ class Output:
         ctx.set_forces(**self.forces_kwargs())
         self.upload(ctx)
         ctx.set_bounce(self._bounce)
+        ctx.set_bodies(self._bodies)
         ctx.set_first_index(self._first_index)
         n = self.npackets
         if keep_trajectory:
@@ -274,6 +327,7 @@ class Output:
         assert self._bounce is None, 'Not set up'            # Output.py:312-315
         ctx = self.context()
         ctx.set_forces(**self.forces_kwargs())
+        ctx.set_bodies(None)
         ctx.upload_soa(np.ascontiguousarray(self.X[STATE_COLS].values.T, dtype=np.float64))
         final, hs = ctx.integrate_var(float(opt.resolution), opt.outeredge)
         ctr = ctx.counters()

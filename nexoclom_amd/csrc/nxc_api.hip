@@ -39,6 +39,7 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int BLOCK_PERSIST = NXC_BLOCK_PERSIST;
+static_assert(NXC_DEV_MAX_MOONS == NXC_MAX_MOONS, "device / ABI moon capacity");
 
 // ---- RCCL, resolved at first use ------------------------------------------------------------
 struct Rccl {
@@ -201,6 +202,11 @@ struct nxc_handle {
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
 
+    bool have_bodies = false;
+    nxc_bodies_desc bodies{};
+    double *d_moonpos = nullptr;     // [n_iter][6 stages][n_moons][x, y]
+    size_t moonpos_cap = 0;
+
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     double *d_reduce = nullptr;      // one double for control-plane reductions
@@ -329,12 +335,43 @@ size_t persist_lds(size_t table_bytes)
     return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
 }
 
-template <bool IMAGE, bool BOUNCE, bool FULL = false>
+// Moon positions at the six stage times of every step: t = t0 - (k + c_n) h, phase phi - omega t,
+// r_m = a (-sin, cos).  Host libm sincos(); the oracle builds the same table the same way.
+int upload_moon_table(nxc_handle *h, double step, int64_t n_iter)
+{
+    static const double cn[6] = {0, 0.2, 0.3, 0.8, 8. / 9., 1.};
+    const nxc_bodies_desc &b = h->bodies;
+    const int nm = b.n_moons;
+    const size_t count = (size_t)(n_iter > 0 ? n_iter : 1) * 12 * (size_t)(nm > 0 ? nm : 1);
+    std::vector<double> pos(count, 0.0);
+    for (int64_t k = 0; k < n_iter; k++)
+        for (int n = 0; n < 6; n++) {
+            const double t = b.t0 - ((double)k + cn[n]) * step;
+            for (int m = 0; m < nm; m++) {
+                const double ang = b.phi[m] - b.omega[m] * t;
+                double *p = &pos[(((size_t)k * 6 + n) * nm + m) * 2];
+                double sn, cs;
+                ::sincos(ang, &sn, &cs);     // the libm pair routine, as the oracle calls it
+                p[0] = -(b.a[m] * sn);
+                p[1] = b.a[m] * cs;
+            }
+        }
+    int rc = ensure(reinterpret_cast<void **>(&h->d_moonpos), &h->moonpos_cap,
+                    count * sizeof(double));
+    if (rc) return rc;
+    // pageable source: the copy is staged before the call returns
+    HIPCHK(hipMemcpyAsync(h->d_moonpos, pos.data(), count * sizeof(double), hipMemcpyHostToDevice,
+                          h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+template <bool IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false>
 int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
                  double *d_final, long long *d_steps)
 {
     int grid = 1, rc;
-    auto kernel = k_const_fused<IMAGE, BOUNCE, FULL>;
+    auto kernel = k_const_fused<IMAGE, BOUNCE, FULL, NBODY>;
     if ((rc = prep_kernel(kernel, lds))) return rc;
     if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, h->n_packets, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
@@ -342,7 +379,8 @@ int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, doubl
                        (int64_t)tables, h->n_packets, h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
                        edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
-                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr);
+                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr,
+                       NBODY ? h->d_moonpos : (const double *)nullptr);
     HIPCHK(hipGetLastError());
     return end_timed(h);
 }
@@ -356,6 +394,13 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
     if ((rc = upload_step(h, step))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     const double edge2 = sqrt_threshold(outeredge);
+    if (h->have_bodies) {
+        if (h->have_bounce)
+            return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
+        if ((rc = upload_moon_table(h, step, n_iter))) return rc;
+        return image ? launch_fused<true, false, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
+                     : launch_fused<false, false, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps);
+    }
     // gravity + radiation pressure + photo-loss, no re-emission: the compile-time specialisation
     const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO && !h->have_bounce;
     if (full)
@@ -368,19 +413,20 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
                           : launch_fused<false, false>(h, tables, lds, n_iter, edge2, d_final, d_steps);
 }
 
-template <bool IMAGE, bool BOUNCE>
+template <bool IMAGE, bool BOUNCE, bool NBODY = false>
 int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double *d_traj,
                 int64_t nrec, double *d_final, long long *d_steps)
 {
     const int64_t n = h->n_packets;
-    auto kernel = k_const_traj<IMAGE, BOUNCE>;
+    auto kernel = k_const_traj<IMAGE, BOUNCE, NBODY>;
     int rc = prep_kernel(kernel, lds);
     if (rc) return rc;
     const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F, h->d_blob,
                        (int64_t)lds, n, h->d_packets, h->first_id, n_iter, edge2, d_traj, nrec,
                        d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
-                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr);
+                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr,
+                       NBODY ? h->d_moonpos : (const double *)nullptr);
     HIPCHK(hipGetLastError());
     return NXC_OK;
 }
@@ -446,7 +492,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
-                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce};
+                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -600,6 +646,48 @@ int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d)
     return NXC_OK;
 }
 
+int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    BodyK &K = h->header.Bd;
+    K = BodyK{};
+    h->have_bodies = false;
+    if (d && (d->n_moons != 0 || d->chx_on)) {
+        if (d->n_moons < 0 || d->n_moons > NXC_MAX_MOONS)
+            return fail(NXC_ERR_ARG, "nxc_bodies_desc: n_moons must be 0..4");
+        for (int m = 0; m < d->n_moons; m++) {
+            if (!(d->a[m] > 0) || !(d->radius[m] >= 0) || !std::isfinite(d->gm[m]) ||
+                !std::isfinite(d->omega[m]) || !std::isfinite(d->phi[m]))
+                return fail(NXC_ERR_ARG, "nxc_bodies_desc: bad moon parameters");
+        }
+        if (d->chx_on && (!(d->chx_width > 0) || !(d->chx_height > 0) || !(d->chx_k0 >= 0) ||
+                          (d->chx_omega != 0 && !(d->chx_omega * d->chx_rho0 > 0))))
+            return fail(NXC_ERR_ARG, "nxc_bodies_desc: bad torus parameters");
+        if (!std::isfinite(d->t0)) return fail(NXC_ERR_ARG, "nxc_bodies_desc: bad t0");
+        h->bodies = *d;
+        K.n_moons = d->n_moons;
+        for (int m = 0; m < d->n_moons; m++) {
+            K.gm[m] = d->gm[m];
+            K.rad2[m] = d->radius[m] * d->radius[m];
+        }
+        K.chx_on = d->chx_on ? 1 : 0;
+        if (K.chx_on) {
+            K.chx_k0 = d->chx_k0; K.chx_rho0 = d->chx_rho0;
+            K.chx_inv_w = 1.0 / d->chx_width; K.chx_inv_h = 1.0 / d->chx_height;
+            K.chx_vel = d->chx_omega != 0 ? 1 : 0;
+            K.chx_omega = d->chx_omega;
+            K.chx_inv_v0 = K.chx_vel ? 1.0 / (d->chx_omega * d->chx_rho0) : 0.0;
+        }
+        h->have_bodies = true;
+    }
+    if (h->d_blob)
+        HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, Bd), &h->header.Bd, sizeof(BodyK),
+                              hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
 int nxc_set_first_index(nxc_handle *h, int64_t first_index)
 {
     if (!h || first_index < 0) return fail(NXC_ERR_ARG, "bad arguments");
@@ -665,6 +753,7 @@ int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const 
     if (rc) return rc;
     if (n < 0 || (n && (!x || !y || !z || !vy || !ax || !ay || !az || !ioniz)))
         return fail(NXC_ERR_ARG, "bad arguments");
+    if (h->have_bodies) return fail(NXC_ERR_STATE, "nxc_state: not available with moons set");
     if (n == 0) return NXC_OK;
     const size_t bytes = (size_t)n * sizeof(double);
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * bytes)))
@@ -691,6 +780,7 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
     int rc = need_forces(h);
     if (rc) return rc;
     if (n < 0 || (n && (!soa_in || !hstep || !soa_out))) return fail(NXC_ERR_ARG, "bad arguments");
+    if (h->have_bodies) return fail(NXC_ERR_STATE, "nxc_rk5_step: not available with moons set");
     if (n == 0) return NXC_OK;
     const size_t col = (size_t)n * sizeof(double);
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 25 * col)))
@@ -880,6 +970,11 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         if (tbytes > free_b)
             return fail(NXC_ERR_ARG, "trajectory buffer does not fit in device memory; run fewer "
                                      "packets per call (the reference chunks too, Input.py:219-222)");
+        if (h->have_bodies) {
+            if (h->have_bounce)
+                return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
+            if ((rc = upload_moon_table(h, step, n_iter))) return rc;
+        }
         double *d_traj = nullptr;
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes));
         if ((rc = upload_step(h, step))) { (void)hipFree(d_traj); return rc; }
@@ -890,7 +985,10 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
         if (e == hipSuccess) {
             const double edge2 = sqrt_threshold(outeredge);
-            if (image)
+            if (h->have_bodies)
+                rc = image ? launch_traj<true, false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
+                           : launch_traj<false, false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
+            else if (image)
                 rc = h->have_bounce ? launch_traj<true, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
                                     : launch_traj<true, false>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
             else
@@ -925,6 +1023,8 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     const int64_t n = h->n_packets;
     if (n < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
     if (!(resolution > 0) || !final_out || max_steps < 1) return fail(NXC_ERR_ARG, "bad arguments");
+    if (h->have_bodies)
+        return fail(NXC_ERR_STATE, "nxc_integrate_var: moons need the constant-step driver");
     const size_t col = (size_t)n * sizeof(double);
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 9 * col)))
         return rc;

@@ -166,6 +166,45 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
     else ion = 0.0;
 }
 
+// Moons and plasma-torus loss (extension: the reference documents the equations,
+// particle_tracking/state.py:5-10,56-70, but refuses such runs, Output.py:153-155).
+//   gravity   a += GM_m (r - r_m) / |r - r_m|^3      for every included moon
+//   loss      rate += k0 exp(-((rho - rho0)/w)^2 - (z/H)^2) [* |v - Omega z^ x r| / (Omega rho0)]
+// Moons move on prescribed circles in the planet's equatorial (x, y) plane.  Their positions
+// at the six stage times of every step come from a host-built table pos[step][stage][moon][2].
+constexpr int NXC_DEV_MAX_MOONS = 4;   // == NXC_MAX_MOONS of the C ABI
+struct BodyK {
+    int n_moons, chx_on, chx_vel, pad_;
+    double gm[NXC_DEV_MAX_MOONS], rad2[NXC_DEV_MAX_MOONS];
+    double chx_k0, chx_rho0, chx_inv_w, chx_inv_h, chx_omega, chx_inv_v0;
+};
+
+// Moon gravity and torus loss added to state_eval's result.  mp: this stage's moon positions
+// (x, y per moon).  Generic-range sqrt / division: moons are approached closely.
+NXC_DEV void bodies_eval(const BodyK &Bd, const double *__restrict__ mp, double x, double y,
+                         double z, double vx, double vy, double vz, double &ax, double &ay,
+                         double &az, double &ion)
+{
+    for (int m = 0; m < Bd.n_moons; m++) {
+        const double dx = x - mp[2 * m], dy = y - mp[2 * m + 1];
+        const double r3 = nxc_cube(nxc_sqrt((dx * dx + dy * dy) + z * z));
+        const double g = Bd.gm[m];
+        ax += nxc_div(g * dx, r3);
+        ay += nxc_div(g * dy, r3);
+        az += nxc_div(g * z, r3);
+    }
+    if (Bd.chx_on) {
+        const double rho = nxc_sqrt(x * x + y * y);
+        const double u = (rho - Bd.chx_rho0) * Bd.chx_inv_w, w = z * Bd.chx_inv_h;
+        double rate = Bd.chx_k0 * nxc_exp(-(u * u + w * w));
+        if (Bd.chx_vel) {
+            const double ux = vx + Bd.chx_omega * y, uy = vy - Bd.chx_omega * x;
+            rate = rate * (nxc_sqrt((ux * ux + uy * uy) + vz * vz) * Bd.chx_inv_v0);
+        }
+        ion += rate;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dormand-Prince tableau (rk5.py:5-18) and one step (rk5.py:21-54)
 // ---------------------------------------------------------------------------------------------
@@ -195,9 +234,10 @@ struct StepW {
 // error estimate |h * sum_{i<6} (B5-B4)_i k_i| (rk5.py:38-46; the 7th stage is left out there).
 // Each stage is accumulated from zero in the order i = 0..n with terms (h*a)*k and the initial
 // state added last (rk5.py:32-36); frac is carried as log(frac) (rk5.py:25,35,50).
-template <bool DELTA, bool UNIFORM_H, bool FULL = false>
+template <bool DELTA, bool UNIFORM_H, bool FULL = false, bool NBODY = false>
 NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double h,
-                      const StepW &W, double (&d)[8])
+                      const StepW &W, double (&d)[8], const BodyK *Bd = nullptr,
+                      const double *__restrict__ mp = nullptr)
 {
     if (UNIFORM_H) h = W.h;
     double kv[6][3], ka[6][3], kl[6];
@@ -208,6 +248,9 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
     for (int n = 0; n < 6; n++) {
         kv[n][0] = vx; kv[n][1] = vy; kv[n][2] = vz;
         state_eval<FULL>(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
+        if (NBODY)
+            bodies_eval(*Bd, mp + n * Bd->n_moons * 2, px, py, pz, vx, vy, vz, ka[n][0], ka[n][1],
+                        ka[n][2], kl[n]);
         // The reference starts each sum from 0.0 (0 + t0): dropped, it can only change the sign
         // of an exactly-zero sum.
         double nx, ny, nz, nvx, nvy, nvz, nlf;
@@ -284,6 +327,7 @@ struct LdsHeader {
     ImageK G;
     StepW W;
     BounceK B;
+    BodyK Bd;
 };
 constexpr int NXC_HEADER_BYTES = (int)((sizeof(LdsHeader) + 31) & ~size_t(31));
 
@@ -437,8 +481,9 @@ NXC_DEV void bounce_packet(const BounceK &B, double (&s)[8], double r2, unsigned
 // the variable driver outeredge itself.
 // With BOUNCE a packet that hits the surface is re-emitted instead of absorbed (Output.py:398-402);
 // the escape test still uses the pre-impact radius, as the reference's tempR does.
-template <bool BOUNCE>
-NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int &nbounce)
+template <bool BOUNCE, bool NBODY = false>
+NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int &nbounce,
+                        const BodyK *Bd = nullptr, const double *__restrict__ mp_end = nullptr)
 {
     const double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
     if (r2 < 1.0) {
@@ -446,6 +491,12 @@ NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int
         else s[7] = 0.0;
     }
     if (r2 > edge2) s[7] = 0.0;
+    if (NBODY) {                    // absorbed by a moon (positions at the end of the step)
+        for (int m = 0; m < Bd->n_moons; m++) {
+            const double dx = s[1] - mp_end[2 * m], dy = s[2] - mp_end[2 * m + 1];
+            if ((dx * dx + dy * dy) + s[3] * s[3] < Bd->rad2[m]) s[7] = 0.0;
+        }
+    }
     if (s[7] < 1e-10) s[7] = 0.0;
     if (s[7] == 0.0) s[0] = 0.0;
 }

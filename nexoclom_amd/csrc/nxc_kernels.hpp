@@ -104,14 +104,14 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
 // ---------------------------------------------------------------------------------------------
 // Lock-step driver with trajectory output.  traj is pre-zeroed: dead packets leave zero records,
 // like the reference's `results` (Output.py:376).
-template <bool IMAGE, bool BOUNCE>
+template <bool IMAGE, bool BOUNCE, bool NBODY = false>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
              int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t first_id,
              int64_t n_iter, double edge2, double *__restrict__ traj, int64_t nrec,
              double *__restrict__ final_out, long long *__restrict__ steps_out,
              double *__restrict__ image, unsigned long long *__restrict__ counts,
-             DevCounters *__restrict__ ctr)
+             DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr)
 {
     stage_tables(blob, stage_bytes);
     const LutView T = lut_view(F.tab);
@@ -135,8 +135,15 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         long long k = 0;
         int nbounce = 0;
         while (alive && k < n_iter) {
-            rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-            apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
+            if (NBODY) {
+                const BodyK *Bd = &lds_header().Bd;
+                const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
+                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+            } else {
+                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
+                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
+            }
             k++; my_steps++;
             if (k < nrec) {
 #pragma unroll
@@ -230,14 +237,15 @@ struct WaveQueue {
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
-template <bool IMAGE, bool BOUNCE, bool FULL>
+template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
               const unsigned *__restrict__ order, int64_t first_id, int64_t n_iter,
               double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ image,
-              unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr)
+              unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr,
+              const double *__restrict__ moon_pos = nullptr)
 {
     stage_tables(blob, stage_bytes);
     const LutView T = lut_view(F.tab);
@@ -265,8 +273,15 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         if (has) {
             bool done = !(s[7] > 0.0) || k >= n_iter;
             if (!done) {
-                rk5_step<false, true, FULL>(F, T, s, 0.0, lds_header().W, d);
-                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
+                if (NBODY) {
+                    const BodyK *Bd = &lds_header().Bd;
+                    const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                    rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
+                    apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+                } else {
+                    rk5_step<false, true, FULL>(F, T, s, 0.0, lds_header().W, d);
+                    apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
+                }
                 k++; my_steps++;
                 if (s[7] > 0.0) {
                     if (IMAGE) {

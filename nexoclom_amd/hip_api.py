@@ -23,7 +23,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
            'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
-           'nxc_set_bounce', 'nxc_set_first_index')
+           'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies')
 
 
 class HipError(RuntimeError):
@@ -67,6 +67,14 @@ class nxc_bounce_desc(C.Structure):
                 ('t1', C.c_double), ('temp_dependent', C.c_int32), ('reserved', C.c_int32),
                 ('nx', C.c_int64), ('ny', C.c_int64), ('tx', _dp), ('ty', _dp), ('coef', _dp),
                 ('seed', C.c_uint64)]
+
+
+class nxc_bodies_desc(C.Structure):
+    _fields_ = [('n_moons', C.c_int32), ('chx_on', C.c_int32), ('gm', C.c_double*4),
+                ('radius', C.c_double*4), ('a', C.c_double*4), ('omega', C.c_double*4),
+                ('phi', C.c_double*4), ('t0', C.c_double), ('chx_k0', C.c_double),
+                ('chx_rho0', C.c_double), ('chx_width', C.c_double), ('chx_height', C.c_double),
+                ('chx_omega', C.c_double)]
 
 
 class nxc_counters(C.Structure):
@@ -213,6 +221,29 @@ class Context:
         d.tx, d.ty, d.coef = _p(tx), _p(ty), _p(coef)
         d.seed = int(cfg['seed']) & 0xffffffffffffffff
         self._check(self.lib.nxc_set_bounce(self._h, C.byref(d)))
+
+    def set_bodies(self, cfg):
+        """cfg: dict(moons=[dict(gm, radius, a, omega, phi), ...], t0, chx=dict(k0, rho0, width,
+        height, omega)|None) in model units (R, s), or None to clear.  Extension beyond the
+        reference (include/nexoclom_hip.h, nxc_bodies_desc)."""
+        if cfg is None:
+            self._check(self.lib.nxc_set_bodies(self._h, None))
+            return
+        d = nxc_bodies_desc()
+        moons = cfg.get('moons', [])
+        if len(moons) > 4:
+            raise HipError('at most 4 moons')
+        d.n_moons = len(moons)
+        for m, mo in enumerate(moons):
+            d.gm[m], d.radius[m], d.a[m] = mo['gm'], mo['radius'], mo['a']
+            d.omega[m], d.phi[m] = mo['omega'], mo['phi']
+        d.t0 = cfg['t0']
+        chx = cfg.get('chx')
+        d.chx_on = int(chx is not None)
+        if chx is not None:
+            d.chx_k0, d.chx_rho0, d.chx_width = chx['k0'], chx['rho0'], chx['width']
+            d.chx_height, d.chx_omega = chx['height'], chx.get('omega', 0.0)
+        self._check(self.lib.nxc_set_bodies(self._h, C.byref(d)))
 
     def set_first_index(self, first_index):
         self._check(self.lib.nxc_set_first_index(self._h, C.c_int64(int(first_index))))

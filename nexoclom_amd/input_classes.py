@@ -346,3 +346,17 @@ class Options(_Spec):
             self.fitted = oparam['fitted'].casefold() == 'True'.casefold()
         else:
             self.fitted = False
+
+        # EXTENSION (no counterpart in the reference, whose charge-exchange term is a
+        # commented stub, state.py:56-70): loss in a plasma torus around the planet,
+        #   rate = chx_rate exp(-((rho - chx_rho0)/chx_width)^2 - (z/chx_height)^2)
+        #          [* |v - v_corotation| / v_corotation(chx_rho0)  if chx_corotation]
+        # lengths in planet radii, chx_rate in 1/s.  Absent chx_rate = no such loss.
+        if 'chx_rate' in oparam:
+            self.chx = {'k0': float(oparam['chx_rate']),
+                        'rho0': float(oparam.get('chx_rho0', 5.9)),
+                        'width': float(oparam.get('chx_width', 1.0)),
+                        'height': float(oparam.get('chx_height', 1.0)),
+                        'corotation': oparam.get('chx_corotation', 'false').casefold() == 'true'}
+        else:
+            self.chx = None

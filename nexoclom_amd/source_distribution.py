@@ -107,8 +107,10 @@ def surface_distribution(outputs):
     else:
         assert False, "Can't get here"
 
-    X_ = xyz_from_lonlat(lon, lat, outputs.inputs.geometry.planet.type == 'Planet',
-                         spatialdist.exobase)
+    # The reference passes geometry.planet.type == 'Planet' (always True, :126).  With a moon
+    # as start point (our extension) the satellite convention of xyz_from_lonlat applies.
+    geo = outputs.inputs.geometry
+    X_ = xyz_from_lonlat(lon, lat, geo.planet.object == geo.startpoint, spatialdist.exobase)
     outputs.X0['x'] = X_[0, :]
     outputs.X0['y'] = X_[1, :]
     outputs.X0['z'] = X_[2, :]

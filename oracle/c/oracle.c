@@ -19,6 +19,9 @@
  *
  * Packet arrays are struct-of-arrays: soa[c*n + i], c = 0..7 = t_remaining,x,y,z,vx,vy,vz,frac.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            /* sincos */
+#endif
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -103,6 +106,59 @@ static inline void state1(const ora_forces *f, double x, double y, double z, dou
     else *ion = 0.0;
 }
 
+/* ---- Extension beyond the reference: moons + plasma-torus loss --------------------------------
+ * The reference documents the equations (state.py:5-10, commented stub :56-70) and refuses such
+ * runs (Output.py:153-155), so this part is OUR definition (include/nexoclom_hip.h,
+ * nxc_bodies_desc) and is "parity unpinned" with respect to the reference. */
+typedef struct {
+    int32_t n_moons, chx_on;
+    double gm[4], radius[4], a[4], omega[4], phi[4];
+    double t0;
+    double chx_k0, chx_rho0, chx_width, chx_height, chx_omega;
+} ora_bodies;
+
+static const double CSTAGE[6] = {0, 0.2, 0.3, 0.8, 8./9., 1.};
+
+static inline void moon_xy(const ora_bodies *b, int m, int64_t k, int stage, double h,
+                           double *mx, double *my)
+{
+    double t = b->t0 - ((double)k + CSTAGE[stage]) * h;
+    double ang = b->phi[m] - b->omega[m] * t, sn, cs;
+    sincos(ang, &sn, &cs);      /* explicitly the libm pair routine: compilers merge sin + cos
+                                   into it at some optimisation levels, and its results are not
+                                   always those of the separate calls */
+    *mx = -(b->a[m] * sn);
+    *my = b->a[m] * cs;
+}
+
+/* adds the moons' gravity and the torus loss to state1()'s result; st = stage state */
+static inline void bodies1(const ora_bodies *b, int64_t k, int stage, double h, const double *st,
+                           double *ax, double *ay, double *az, double *ion)
+{
+    double x = st[1], y = st[2], z = st[3];
+    for (int m = 0; m < b->n_moons; m++) {
+        double mx, my;
+        moon_xy(b, m, k, stage, h, &mx, &my);
+        double dx = x - mx, dy = y - my;
+        double r3 = ora_cube(sqrt((dx*dx + dy*dy) + z*z));
+        *ax += b->gm[m] * dx / r3;
+        *ay += b->gm[m] * dy / r3;
+        *az += b->gm[m] * z / r3;
+    }
+    if (b->chx_on) {
+        double inv_w = 1.0 / b->chx_width, inv_h = 1.0 / b->chx_height;
+        double rho = sqrt(x*x + y*y);
+        double u = (rho - b->chx_rho0) * inv_w, w = z * inv_h;
+        double rate = b->chx_k0 * ora_exp(-(u*u + w*w));
+        if (b->chx_omega != 0) {
+            double inv_v0 = 1.0 / (b->chx_omega * b->chx_rho0);
+            double ux = st[4] + b->chx_omega * y, uy = st[5] - b->chx_omega * x;
+            rate = rate * (sqrt((ux*ux + uy*uy) + st[6]*st[6]) * inv_v0);
+        }
+        *ion += rate;
+    }
+}
+
 void ora_state(const ora_forces *f, int64_t n, const double *x, const double *y, const double *z,
                const double *vy, double *ax, double *ay, double *az, double *ion)
 {
@@ -112,7 +168,8 @@ void ora_state(const ora_forces *f, int64_t n, const double *x, const double *y,
 }
 
 /* One step for one packet.  s[8] in/out; d[8] (nullable) receives |h * sum_{i<6} (b5-b4)_i k_i|. */
-static void rk5_one(const ora_forces *f, double *s, double h, double *d)
+static void rk5_body(const ora_forces *f, const ora_bodies *b, int64_t k, double *s, double h,
+                     double *d)
 {
     double y0[8], st[8], kv[6][3], ka[6][3], kl[6];
     memcpy(y0, s, sizeof y0);
@@ -121,6 +178,7 @@ static void rk5_one(const ora_forces *f, double *s, double h, double *d)
     for (int n = 0; n < 6; n++) {
         kv[n][0] = st[4]; kv[n][1] = st[5]; kv[n][2] = st[6];
         state1(f, st[1], st[2], st[3], st[5], &ka[n][0], &ka[n][1], &ka[n][2], &kl[n]);
+        if (b) bodies1(b, k, n, h, st, &ka[n][0], &ka[n][1], &ka[n][2], &kl[n]);
         double nx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         nx[0] = -h * CN[n+1];
         for (int i = 0; i <= n; i++) {
@@ -149,6 +207,11 @@ static void rk5_one(const ora_forces *f, double *s, double h, double *d)
     memcpy(s, st, sizeof st);
 }
 
+static void rk5_one(const ora_forces *f, double *s, double h, double *d)
+{
+    rk5_body(f, NULL, 0, s, h, d);
+}
+
 void ora_rk5_step(const ora_forces *f, int64_t n, const double *in, const double *h, double *out,
                   double *delta)
 {
@@ -169,6 +232,23 @@ static inline void fate(double *s, double outeredge, int r_squared)
     double rr = r_squared ? r2 : sqrt(r2);
     if (r_squared ? (rr < 1.0) : ((rr - 1.0) < 0.0)) s[7] = 0.0;
     if (rr > outeredge) s[7] = 0.0;
+    if (s[7] < 1e-10) s[7] = 0.0;
+    if (s[7] == 0.0) s[0] = 0.0;
+}
+
+/* constant-driver fate plus absorption by a moon (positions at the end of step k) */
+static inline void fate_bodies(double *s, double outeredge, const ora_bodies *b, int64_t k, double h)
+{
+    double r2 = (s[1]*s[1] + s[2]*s[2]) + s[3]*s[3];
+    double rr = sqrt(r2);
+    if ((rr - 1.0) < 0.0) s[7] = 0.0;
+    if (rr > outeredge) s[7] = 0.0;
+    for (int m = 0; m < b->n_moons; m++) {
+        double mx, my;
+        moon_xy(b, m, k, 5, h, &mx, &my);
+        double dx = s[1] - mx, dy = s[2] - my;
+        if ((dx*dx + dy*dy) + s[3]*s[3] < b->radius[m] * b->radius[m]) s[7] = 0.0;
+    }
     if (s[7] < 1e-10) s[7] = 0.0;
     if (s[7] == 0.0) s[0] = 0.0;
 }
@@ -235,7 +315,8 @@ void ora_image(const ora_image_desc *g, int64_t p, const double *x, const double
  * img (nullable): every stored record with frac > 0 (records 0..n_iter, compress=True rule of
  * Output.py:523-524) is binned.  Returns the number of particle-steps.  n_threads <= 1 keeps the
  * image accumulation in exact sample order. */
-int64_t ora_integrate_const(const ora_forces *f, int64_t n, const double *soa0, double step,
+static int64_t integrate_const_impl(const ora_forces *f, const ora_bodies *b, int64_t n,
+                                    const double *soa0, double step,
                             int64_t n_iter, double outeredge, double *traj, int64_t nrec,
                             double *final, int64_t *steps, const ora_image_desc *img,
                             double *image, uint64_t *counts, int n_threads)
@@ -268,8 +349,13 @@ int64_t ora_integrate_const(const ora_forces *f, int64_t n, const double *soa0, 
             int alive = s[7] > 0;
             if (img && alive) image_sample(img, s[1], s[2], s[3], s[5], s[7], im, ct);
             while (alive && k < n_iter) {
-                rk5_one(f, s, step, NULL);
-                fate(s, outeredge, 0);
+                if (b) {
+                    rk5_body(f, b, k, s, step, NULL);
+                    fate_bodies(s, outeredge, b, k, step);
+                } else {
+                    rk5_one(f, s, step, NULL);
+                    fate(s, outeredge, 0);
+                }
                 k++; work++;
                 if (traj && k < nrec)
                     for (int c = 0; c < 8; c++) traj[((size_t)c*nrec + k)*n + i] = s[c];
@@ -289,6 +375,25 @@ int64_t ora_integrate_const(const ora_forces *f, int64_t n, const double *soa0, 
         free(pim); free(pct);
     }
     return work;
+}
+
+int64_t ora_integrate_const(const ora_forces *f, int64_t n, const double *soa0, double step,
+                            int64_t n_iter, double outeredge, double *traj, int64_t nrec,
+                            double *final, int64_t *steps, const ora_image_desc *img,
+                            double *image, uint64_t *counts, int n_threads)
+{
+    return integrate_const_impl(f, NULL, n, soa0, step, n_iter, outeredge, traj, nrec, final,
+                                steps, img, image, counts, n_threads);
+}
+
+int64_t ora_integrate_const_bodies(const ora_forces *f, const ora_bodies *b, int64_t n,
+                                   const double *soa0, double step, int64_t n_iter,
+                                   double outeredge, double *traj, int64_t nrec, double *final,
+                                   int64_t *steps, const ora_image_desc *img, double *image,
+                                   uint64_t *counts, int n_threads)
+{
+    return integrate_const_impl(f, b, n, soa0, step, n_iter, outeredge, traj, nrec, final, steps,
+                                img, image, counts, n_threads);
 }
 
 /* Variable-step driver, one packet at a time (Output.py:221-359).  out [8][n]; hstore (nullable)

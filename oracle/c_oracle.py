@@ -28,6 +28,14 @@ class _Image(C.Structure):
                 ('line_v', _dp*4), ('line_g', _dp*4)]
 
 
+class _Bodies(C.Structure):
+    _fields_ = [('n_moons', C.c_int32), ('chx_on', C.c_int32), ('gm', C.c_double*4),
+                ('radius', C.c_double*4), ('a', C.c_double*4), ('omega', C.c_double*4),
+                ('phi', C.c_double*4), ('t0', C.c_double), ('chx_k0', C.c_double),
+                ('chx_rho0', C.c_double), ('chx_width', C.c_double), ('chx_height', C.c_double),
+                ('chx_omega', C.c_double)]
+
+
 def build(force=False):
     so = os.path.join(_HERE, '_build', 'liboracle.so')
     if force or not os.path.exists(so):
@@ -49,6 +57,7 @@ class COracle:
         name = 'liboracle_libm.so' if libm else 'liboracle.so'
         self.lib = C.CDLL(os.path.join(_HERE, '_build', name))
         self.lib.ora_integrate_const.restype = C.c_int64
+        self.lib.ora_integrate_const_bodies.restype = C.c_int64
         self.lib.ora_integrate_var.restype = C.c_int64
         self.lib.ora_max_threads.restype = C.c_int
         self._keep = []
@@ -105,8 +114,21 @@ class COracle:
                               _ptr(delta) if want_delta else None)
         return out.T.copy(), (delta.T.copy() if want_delta else None)
 
+    @staticmethod
+    def bodies(b):
+        """b: oracle.np_oracle.Bodies."""
+        d = _Bodies()
+        d.n_moons, d.chx_on = len(b.gm), int(b.chx_on)
+        for m in range(len(b.gm)):
+            d.gm[m], d.radius[m], d.a[m] = b.gm[m], b.radius[m], b.a[m]
+            d.omega[m], d.phi[m] = b.omega[m], b.phi[m]
+        d.t0 = b.t0
+        d.chx_k0, d.chx_rho0, d.chx_width = b.chx_k0, b.chx_rho0, b.chx_width
+        d.chx_height, d.chx_omega = b.chx_height, b.chx_omega
+        return d
+
     def integrate_const(self, f, X0, step, n_iter, outeredge, nrec=0, img=None, threads=1,
-                        want_final=True):
+                        want_final=True, bodies=None):
         """Returns dict(work, traj (8,nrec,n)|None, final (N,8), steps (N,), image, counts)."""
         ff = self.forces(f)
         n = X0.shape[0]
@@ -118,8 +140,12 @@ class COracle:
         if img is not None:
             image = np.zeros((img.nx, img.nz))
             counts = np.zeros((img.nx, img.nz), dtype=np.uint64)
-        work = self.lib.ora_integrate_const(
-            C.byref(ff), C.c_int64(n), _ptr(soa), C.c_double(step), C.c_int64(n_iter),
+        fn, lead = self.lib.ora_integrate_const, (C.byref(ff),)
+        if bodies is not None:
+            bb = self.bodies(bodies)
+            fn, lead = self.lib.ora_integrate_const_bodies, (C.byref(ff), C.byref(bb))
+        work = fn(
+            *lead, C.c_int64(n), _ptr(soa), C.c_double(step), C.c_int64(n_iter),
             C.c_double(outeredge), _ptr(traj) if nrec else None, C.c_int64(nrec),
             _ptr(final) if want_final else None, steps.ctypes.data_as(C.c_void_p),
             C.byref(img) if img is not None else None,

@@ -595,3 +595,113 @@ def constant_step_driver_bounce(f: Forces, X0, endtime, step, outeredge, cfg, fi
         ct += 1
         curtime -= step
     return results, nbounce, work
+
+
+# =================================================================================================
+# EXTENSION beyond the reference: moons + plasma-torus loss (BASELINE config 5).
+# The reference documents the equations (particle_tracking/state.py:5-10; commented
+# charge-exchange stub :56-70) but asserts 'Not set up' for planets with moons
+# (Output.py:153-155), so there is nothing to pin this against: "parity unpinned".  This is
+# the definition the HIP path implements (include/nexoclom_hip.h, nxc_bodies_desc).
+# =================================================================================================
+@dataclass
+class Bodies:
+    gm: tuple = ()          # R^3/s^2, negative (same sign convention as Forces.GM)
+    radius: tuple = ()      # R
+    a: tuple = ()           # orbit radius, R
+    omega: tuple = ()       # rad/s
+    phi: tuple = ()         # orbital phase at t_remaining = 0 (0 = superior conjunction, +y)
+    t0: float = 0.          # t_remaining of every packet at the start
+    chx_on: bool = False
+    chx_k0: float = 0.
+    chx_rho0: float = 1.
+    chx_width: float = 1.
+    chx_height: float = 1.
+    chx_omega: float = 0.
+
+
+_STAGE_C = (0., 0.2, 0.3, 0.8, 8./9., 1.)
+
+
+def moon_xy(b: Bodies, m, k, stage, h):
+    """Position of moon m at stage `stage` of step k: circle in the (x, y) plane, phase
+    phi - omega*t at t_remaining = t; phi = pi/2 is over the dawn terminator (-x)."""
+    import math
+    t = b.t0 - (float(k) + _STAGE_C[stage])*h
+    ang = b.phi[m] - b.omega[m]*t
+    return -(b.a[m]*math.sin(ang)), b.a[m]*math.cos(ang)
+
+
+def state_bodies(x, f: Forces, b: Bodies, k, stage, h):
+    accel, ioniz = state(x, f)
+    px, py, pz = x[:, 1], x[:, 2], x[:, 3]
+    for m in range(len(b.gm)):
+        mx, my = moon_xy(b, m, k, stage, h)
+        dx, dy = px - mx, py - my
+        r3 = np.sqrt((dx*dx + dy*dy) + pz*pz)**3
+        accel[:, 0] += b.gm[m]*dx/r3
+        accel[:, 1] += b.gm[m]*dy/r3
+        accel[:, 2] += b.gm[m]*pz/r3
+    if b.chx_on:
+        inv_w, inv_h = 1.0/b.chx_width, 1.0/b.chx_height
+        rho = np.sqrt(px*px + py*py)
+        u, w = (rho - b.chx_rho0)*inv_w, pz*inv_h
+        rate = b.chx_k0*np.exp(-(u*u + w*w))
+        if b.chx_omega != 0:
+            inv_v0 = 1.0/(b.chx_omega*b.chx_rho0)
+            ux, uy = x[:, 4] + b.chx_omega*py, x[:, 5] - b.chx_omega*px
+            rate = rate*(np.sqrt((ux*ux + uy*uy) + x[:, 6]*x[:, 6])*inv_v0)
+        ioniz = ioniz + rate
+    return accel, ioniz
+
+
+def rk5_bodies(f: Forces, b: Bodies, X0, h, k):
+    """rk5() with the time-dependent extra terms; h scalar, k the step index."""
+    n = X0.shape[0]
+    y0 = X0.copy()
+    y0[:, 7] = np.log(y0[:, 7])
+    stage = y0
+    kv, ka, kl = [], [], []
+    for s in range(6):
+        acc, ion = state_bodies(stage, f, b, k, s, h)
+        kv.append(stage[:, 4:7].copy())
+        ka.append(acc)
+        kl.append(ion)
+        nxt = np.zeros_like(y0)
+        nxt[:, 0] = -h*C_NODES[s+1]
+        for i in range(s+1):
+            w = h*A_TAB[s+1, i]
+            nxt[:, 1:4] += w*kv[i]
+            nxt[:, 4:7] += w*ka[i]
+            nxt[:, 7] -= w*kl[i]
+        nxt += y0
+        stage = nxt
+    stage[:, 7] = np.exp(stage[:, 7])
+    return stage
+
+
+def constant_step_driver_bodies(f: Forces, b: Bodies, X0, endtime, step, outeredge):
+    """constant_step_driver with moons: lock-step, so the step index is shared."""
+    n = X0.shape[0]
+    nsteps, n_iter = n_output_steps(endtime, step)
+    results = np.zeros((n, 8, nsteps))
+    results[:, :, 0] = X0
+    alive = results[:, 7, 0] > 0
+    work = 0
+    for k in range(min(n_iter, nsteps - 1)):
+        if not alive.any():
+            break
+        Xn = rk5_bodies(f, b, results[alive, :, k], step, k)
+        work += Xn.shape[0]
+        r = np.sqrt((Xn[:, 1]*Xn[:, 1] + Xn[:, 2]*Xn[:, 2]) + Xn[:, 3]*Xn[:, 3])
+        Xn[(r - 1.) < 0, 7] = 0.
+        Xn[r > outeredge, 7] = 0.
+        for m in range(len(b.gm)):
+            mx, my = moon_xy(b, m, k, 5, step)
+            dx, dy = Xn[:, 1] - mx, Xn[:, 2] - my
+            Xn[(dx*dx + dy*dy) + Xn[:, 3]*Xn[:, 3] < b.radius[m]*b.radius[m], 7] = 0.
+        Xn[Xn[:, 7] < 1e-10, 7] = 0.
+        Xn[Xn[:, 7] == 0, 0] = 0.
+        results[alive, :, k+1] = Xn
+        alive = results[:, 7, k+1] > 0
+    return results, work

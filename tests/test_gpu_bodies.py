@@ -1,0 +1,220 @@
+"""Moons + plasma-torus loss (BASELINE config 5; extension beyond the reference, which asserts
+'Not set up' for planets with moons, Output.py:153-155 -- PARITY UNPINNED with respect to the
+reference).  Checked here: (1) HIP through the C ABI == C oracle bit for bit; (2) the limits that
+connect the extension to the pinned single-body path; (3) physics: the Jacobi integral of the
+prescribed-circle three-body problem and the analytic torus loss."""
+import os
+
+import numpy as np
+import pytest
+
+from nexoclom_amd.hip_api import HipError
+from oracle import np_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def bodies_cfg(b):
+    return dict(moons=[dict(gm=b.gm[m], radius=b.radius[m], a=b.a[m], omega=b.omega[m],
+                            phi=b.phi[m]) for m in range(len(b.gm))], t0=b.t0,
+                chx=dict(k0=b.chx_k0, rho0=b.chx_rho0, width=b.chx_width, height=b.chx_height,
+                         omega=b.chx_omega) if b.chx_on else None)
+
+
+def random_bodies(rng, f, endtime):
+    nm = int(rng.integers(0, 4))
+    chx = bool(rng.random() < 0.7) or nm == 0
+    a = np.sort(rng.uniform(2.0, 7.0, nm))
+    return O.Bodies(gm=tuple(f.GM*rng.uniform(1e-4, 3e-2, nm)), radius=tuple(rng.uniform(0.02, 0.3, nm)),
+                    a=tuple(a), omega=tuple(np.sqrt(-f.GM/a**3)), phi=tuple(rng.uniform(0, 2*np.pi, nm)),
+                    t0=endtime, chx_on=chx, chx_k0=float(rng.uniform(1e-5, 3e-4)),
+                    chx_rho0=float(rng.uniform(2, 5)), chx_width=float(rng.uniform(0.5, 2)),
+                    chx_height=float(rng.uniform(0.3, 1.5)),
+                    chx_omega=float(rng.choice([0.0, 2e-4])))
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_bodies_parity_with_c_oracle(ctx, coracle, seed):
+    rng = np.random.default_rng(500 + seed)
+    f = H.mercury_forces('Na', 1.3, True, bool(seed % 2 == 0), 0.0 if seed % 3 else 4000.0)
+    endtime, step = float(rng.choice([6000., 9000.])), float(rng.choice([30., 45.5]))
+    b = random_bodies(rng, f, endtime)
+    n = 1500
+    X0 = H.sample_x0(n, 10 + seed, endtime, vprob=3.0, delv=1.2)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    n_iter = min(n_iter, nsteps - 1)
+    im = H.image_setup(f, 'radiance', dims=(48, 40), width=(16., 16.))
+    H.set_ctx_forces(ctx, f)
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'])
+    try:
+        ctx.set_bodies(bodies_cfg(b))
+        ctx.upload_packets(X0)
+        g = ctx.integrate_const(step, n_iter, 9.0, image=True, want_final=True, want_steps=True)
+        image, counts = ctx.image_download()
+        ctr = ctx.counters()
+        desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                                  im['xedges'], im['zedges'])
+        c = coracle.integrate_const(f, X0, step, n_iter, 9.0, img=desc, threads=4, bodies=b)
+        assert np.array_equal(g['steps'], c['steps'])
+        assert np.array_equal(g['final'], c['final'])
+        assert ctr['particle_steps'] == c['work'] and ctr['nonfinite'] == 0
+        assert np.array_equal(counts, c['counts'])
+        np.testing.assert_allclose(image, c['image'], rtol=1e-11, atol=0)
+        m = 300
+        ctx.upload_packets(X0[:m])
+        t = ctx.integrate_const(step, n_iter, 9.0, nrec=nsteps, want_final=True)
+        ct = coracle.integrate_const(f, X0[:m], step, n_iter, 9.0, nrec=nsteps, bodies=b)
+        assert np.array_equal(t['traj'], ct['traj'])
+        # the moons / the torus change the answer (the test is not vacuous)
+        c1 = coracle.integrate_const(f, X0[:m], step, n_iter, 9.0, nrec=nsteps)
+        assert not np.array_equal(ct['traj'], c1['traj'])
+    finally:
+        ctx.set_bodies(None)
+
+
+def test_massless_moon_equals_single_body_path(ctx):
+    """gm = 0, radius = 0, no torus: the extension kernels reproduce the pinned path."""
+    f = H.mercury_forces('Na', 1.3)
+    X0 = H.sample_x0(2000, 3, 9000.)
+    H.set_ctx_forces(ctx, f)
+    ctx.upload_packets(X0)
+    ref = ctx.integrate_const(30., 300, 12., want_final=True, want_steps=True)
+    b = O.Bodies(gm=(0.0,), radius=(0.0,), a=(3.0,), omega=(1e-4,), phi=(0.5,), t0=9000.)
+    try:
+        ctx.set_bodies(bodies_cfg(b))
+        ctx.upload_packets(X0)
+        got = ctx.integrate_const(30., 300, 12., want_final=True, want_steps=True)
+    finally:
+        ctx.set_bodies(None)
+    assert np.array_equal(got['steps'], ref['steps'])
+    assert np.array_equal(got['final'], ref['final'])
+
+
+def test_jacobi_integral_is_conserved(ctx):
+    """Planet + one moon on a prescribed circle: J = v^2/2 + U - omega (x vy - y vx) is a
+    constant of the motion (potential stationary in the frame rotating with the moon)."""
+    f = H.mercury_forces('Na', 1.3, gravity=True, radpres=False, lifetime=1e30)
+    a, gm_m = 4.0, f.GM*0.02
+    omega = np.sqrt(-f.GM/a**3)
+    endtime, step = 40000., 10.
+    b = O.Bodies(gm=(gm_m,), radius=(0.05,), a=(a,), omega=(omega,), phi=(0.7,), t0=endtime)
+    rng = np.random.default_rng(2)
+    n = 512
+    X0 = np.zeros((n, 8))
+    X0[:, 0], X0[:, 7] = endtime, 1.0
+    r = rng.uniform(1.6, 3.0, n)
+    th = rng.uniform(0, 2*np.pi, n)
+    X0[:, 1], X0[:, 2], X0[:, 3] = r*np.cos(th), r*np.sin(th), rng.uniform(-0.3, 0.3, n)
+    vc = np.sqrt(-f.GM/r)*rng.uniform(0.8, 1.1, n)
+    X0[:, 4], X0[:, 5], X0[:, 6] = -vc*np.sin(th), vc*np.cos(th), rng.uniform(-0.1, 0.1, n)*vc
+
+    def jacobi(X, t_rem):
+        ang = b.phi[0] - omega*t_rem
+        mx, my = -a*np.sin(ang), a*np.cos(ang)
+        U = f.GM/np.linalg.norm(X[:, 1:4], axis=1) \
+            + gm_m/np.sqrt((X[:, 1]-mx)**2 + (X[:, 2]-my)**2 + X[:, 3]**2)
+        return 0.5*(X[:, 4:7]**2).sum(1) + U - omega*(X[:, 1]*X[:, 5] - X[:, 2]*X[:, 4])
+
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    H.set_ctx_forces(ctx, f)
+    try:
+        ctx.set_bodies(bodies_cfg(b))
+        ctx.upload_packets(X0)
+        g = ctx.integrate_const(step, n_iter, 1e30, want_final=True, want_steps=True)
+    finally:
+        ctx.set_bodies(None)
+    alive = g['final'][:, 7] > 0
+    assert alive.sum() > 0.8*n
+    j0 = jacobi(X0, endtime)[alive]
+    j1 = jacobi(g['final'][alive], g['final'][alive, 0])
+    assert np.abs(g['final'][alive, 0]).max() < 1e-6          # integrated to t_remaining = 0
+    np.testing.assert_allclose(j1, j0, rtol=2e-7)
+    # and the moon does act: energy alone is not conserved to that level
+    e0 = (0.5*(X0[:, 4:7]**2).sum(1) + f.GM/np.linalg.norm(X0[:, 1:4], axis=1))[alive]
+    F = g['final'][alive]
+    e1 = 0.5*(F[:, 4:7]**2).sum(1) + f.GM/np.linalg.norm(F[:, 1:4], axis=1)
+    assert np.abs(e1/e0 - 1).max() > 1e-4
+
+
+def test_torus_loss_matches_the_analytic_decay(ctx):
+    """Circular orbit through the torus centre, no velocity dependence: frac = exp(-k0 t)."""
+    f = H.mercury_forces('Na', 1.3, gravity=True, radpres=False, lifetime=1e30)
+    rho0, k0, endtime, step = 3.0, 2e-4, 6000., 20.
+    b = O.Bodies(t0=endtime, chx_on=True, chx_k0=k0, chx_rho0=rho0, chx_width=1.0, chx_height=1.0)
+    X0 = np.zeros((4, 8))
+    X0[:, 0], X0[:, 7] = endtime, 1.0
+    X0[:, 1] = rho0
+    X0[:, 5] = np.sqrt(-f.GM/rho0)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    H.set_ctx_forces(ctx, f)
+    try:
+        ctx.set_bodies(bodies_cfg(b))
+        ctx.upload_packets(X0)
+        g = ctx.integrate_const(step, n_iter, 1e30, want_final=True)
+        # with the relative-speed factor: a packet co-rotating with the plasma loses nothing
+        b2 = O.Bodies(t0=endtime, chx_on=True, chx_k0=k0, chx_rho0=rho0, chx_width=1.0,
+                      chx_height=1.0, chx_omega=float(np.sqrt(-f.GM/rho0**3)))
+        ctx.set_bodies(bodies_cfg(b2))
+        ctx.upload_packets(X0)
+        g2 = ctx.integrate_const(step, n_iter, 1e30, want_final=True)
+    finally:
+        ctx.set_bodies(None)
+    # (the constant 1/lifetime = 1e-30 contributes nothing visible)
+    np.testing.assert_allclose(g['final'][:, 7], np.exp(-k0*endtime), rtol=1e-9)
+    np.testing.assert_allclose(g2['final'][:, 7], 1.0, rtol=1e-7)   # |v - v_corot| ~ 1e-5 v
+
+
+def test_other_entry_points_refuse_moons(ctx):
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    b = O.Bodies(gm=(f.GM*0.01,), radius=(0.05,), a=(3.0,), omega=(1e-4,), phi=(0.,), t0=100.)
+    X0 = H.sample_x0(64, 1, 100.)
+    try:
+        ctx.set_bodies(bodies_cfg(b))
+        with pytest.raises(HipError):
+            ctx.state(X0[:, 1], X0[:, 2], X0[:, 3], X0[:, 5])
+        with pytest.raises(HipError):
+            ctx.rk5_step(X0, 30.)
+        ctx.upload_packets(X0)
+        with pytest.raises(HipError):
+            ctx.integrate_var(1e-4, 10.)
+    finally:
+        ctx.set_bodies(None)
+    ctx.state(X0[:, 1], X0[:, 2], X0[:, 3], X0[:, 5])         # cleared: works again
+
+
+def test_config5_inputfile_end_to_end(ctx, coracle):
+    """Na from Io with Io + Europa + torus, through Input/ModelImage, against the C oracle fed
+    with the same X0 and tables."""
+    from nexoclom_amd import Input, ModelImage
+    from nexoclom_amd.Output import Output, n_output_steps
+    import nexoclom_amd
+    infile = os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles', 'Na.io.torus.input')
+    inputs = Input(infile)
+    inputs.options.endtime = type(inputs.options.endtime)(36000., 's')
+    n = 3000
+    params = {'quantity': 'radiance', 'dims': '64,64', 'width': '24,24'}
+    img = ModelImage(inputs, params, npackets=n, seed=5, context=ctx)
+    out = Output(inputs, n, seed=5, integrate=False, save=False, context=ctx)
+    bd = out._bodies
+    b = O.Bodies(gm=tuple(m['gm'] for m in bd['moons']), radius=tuple(m['radius'] for m in bd['moons']),
+                 a=tuple(m['a'] for m in bd['moons']), omega=tuple(m['omega'] for m in bd['moons']),
+                 phi=tuple(m['phi'] for m in bd['moons']), t0=bd['t0'], chx_on=True,
+                 chx_k0=bd['chx']['k0'], chx_rho0=bd['chx']['rho0'], chx_width=bd['chx']['width'],
+                 chx_height=bd['chx']['height'], chx_omega=bd['chx']['omega'])
+    kw = out.forces_kwargs()
+    f = O.Forces(GM=kw['GM'], vrplanet=kw['vrplanet'], gravity=kw['gravity'], radpres=kw['radpres'],
+                 lifetime=kw['lifetime'], photo=kw['photo'], v_tab=kw['v_tab'], a_tab=kw['a_tab'])
+    nsteps, n_iter = n_output_steps(36000., float(inputs.options.step_size))
+    desc = coracle.image_desc(img.image_rotation(), f.vrplanet, float(img.Apix), 'radiance',
+                              img.g_tables(out.aplanet), img.xedges, img.zedges, downcast=True)
+    c = coracle.integrate_const(f, out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values,
+                                float(inputs.options.step_size), n_iter, inputs.options.outeredge,
+                                img=desc, threads=4, bodies=b)
+    assert np.array_equal(img.packet_image, c['counts'].astype(float))
+    np.testing.assert_allclose(img.image, c['image']*img.atoms_per_packet, rtol=1e-10)
+    assert img.packet_image.sum() > 0.5*n
+    ctx.set_bodies(None)
