@@ -227,6 +227,22 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
 int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                         uint32_t flags, double *traj_out, int64_t nrec, double *final_out,
                         int64_t *steps_out);
+/* The same trajectories in the form Output.save() keeps them (compress=True, Output.py:523-524):
+ * only the records with frac > 0, packet-major (all records of packet 0 in step order, then packet
+ * 1, ...), i.e. the row order of the reference's X frame after the frac > 0 filter.  A packet's
+ * live records are a prefix of its step axis, so the zero padding of the dense [8][nrec][n] array
+ * (typically > 90 % of it) is never materialised or transferred.
+ *   nxc_integrate_const_rows : pass 1 (persistent kernel) counts the live records per packet;
+ *                              lengths_out int64[n] (nullable), *total_out = their sum.
+ *   nxc_rows_fetch           : pass 2 (lock-step kernel) re-integrates and writes rows_out, host
+ *                              [9][total]: the 8 state columns and lossfrac accumulated as
+ *                              (lossfrac + frac_before) - frac_after per step (Output.py:420-421),
+ *                              starting from 0 (the reference's starts from uninitialised memory,
+ *                              Output.py:378).  Must follow nxc_integrate_const_rows on the same
+ *                              resident packets. */
+int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                             int64_t *lengths_out, int64_t *total_out);
+int nxc_rows_fetch(nxc_handle *h, double *rows_out);
 /* Same launch without any host transfer or synchronisation (bench / pipelining). */
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags);

@@ -298,7 +298,26 @@ class Output:
         ctx.set_bodies(self._bodies)
         ctx.set_first_index(self._first_index)
         n = self.npackets
-        if keep_trajectory:
+        if keep_trajectory and self.compress:
+            # compress=True keeps only the rows with frac > 0 (Output.py:523-524, applied by the
+            # save() every reference Output ends in): the kernel delivers exactly those rows,
+            # packet-major like the filtered frame, instead of the >90 % zero-padded dense array
+            res = ctx.integrate_const_rows(step, n_iter, opt.outeredge)
+            ctr = ctx.counters()
+            self._raise_on_counters(ctr)
+            assert ctr.get('unfinished', 0) == 0, 'row passes disagree'
+            rows, lengths = res['rows'], res['lengths']
+            X = pd.DataFrame()
+            X['Index'] = np.repeat(np.arange(n, dtype=np.int64), lengths)
+            for k, name in enumerate(STATE_COLS):
+                X[name] = rows[k]
+            X['lossfrac'] = rows[8]
+            # the frac > 0 filter leaves the surviving rows' original labels (packet*nsteps + ct)
+            starts = np.cumsum(lengths) - lengths
+            X.index = (X['Index'].values*self.nsteps
+                       + (np.arange(len(X), dtype=np.int64) - np.repeat(starts, lengths)))
+            self.X = X
+        elif keep_trajectory:
             res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)
             self._raise_on_counters(ctx.counters())
             traj = res['traj']                               # (8, nsteps, N)
@@ -308,11 +327,14 @@ class Output:
                 X[name] = np.ascontiguousarray(traj[k].T).reshape(n*self.nsteps)
             frac = traj[7].T                                 # (N, nsteps)
             # lossfrac[:, ct] = lossfrac[:, ct-1] + frac[:, ct-1] - frac[:, ct] while the
-            # packet was active at ct-1 (Output.py:420-421)
-            d = np.zeros_like(frac)
-            active_prev = frac[:, :-1] > 0
-            d[:, 1:] = np.where(active_prev, frac[:, :-1] - frac[:, 1:], 0.0)
-            X['lossfrac'] = np.cumsum(d, axis=1).reshape(n*self.nsteps)
+            # packet was active at ct-1 (Output.py:420-421), evaluated left to right
+            lossfrac = np.zeros_like(frac)
+            for ct in range(1, self.nsteps):
+                act = frac[:, ct-1] > 0
+                if not act.any():
+                    break
+                lossfrac[act, ct] = (lossfrac[act, ct-1] + frac[act, ct-1]) - frac[act, ct]
+            X['lossfrac'] = lossfrac.reshape(n*self.nsteps)
             self.X = X
         else:
             ctx.integrate_const(step, n_iter, opt.outeredge)

@@ -202,6 +202,13 @@ struct nxc_handle {
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
 
+    // compact-rows protocol (nxc_integrate_const_rows -> nxc_rows_fetch)
+    long long *d_offsets = nullptr;
+    size_t offsets_cap = 0;
+    long long rows_total = -1;
+    double rows_step = 0, rows_edge = 0;
+    int64_t rows_n_iter = 0, rows_n = 0;
+
     bool have_bodies = false;
     nxc_bodies_desc bodies{};
     double *d_moonpos = nullptr;     // [n_iter][6 stages][n_moons][x, y]
@@ -492,7 +499,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
-                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos};
+                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -855,6 +862,7 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->n_packets = n;
     h->first_id = 0;
+    h->rows_total = -1;
     return NXC_OK;
 }
 
@@ -913,6 +921,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     h->n_packets = n;
+    h->rows_total = -1;
     h->first_id = d->first_index;
     const double vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
                                             : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
@@ -1012,6 +1021,107 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         HIPCHK(hipMemcpyAsync(steps_out, d_steps, (size_t)n * sizeof(long long),
                               hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge,
+                             int64_t *lengths_out, int64_t *total_out)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    const int64_t n = h->n_packets;
+    if (n < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
+    if (!(step > 0) || n_iter < 0 || !total_out) return fail(NXC_ERR_ARG, "bad arguments");
+    h->rows_total = -1;
+    const size_t col = (size_t)n * sizeof(double);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col))) return rc;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
+                     (size_t)n * sizeof(long long))))
+        return rc;
+    if ((rc = launch_const(h, step, n_iter, outeredge, false, h->d_scratch, h->d_steps))) return rc;
+    std::vector<long long> steps((size_t)n), off((size_t)n + 1);
+    std::vector<double> frac((size_t)n);
+    HIPCHK(hipMemcpyAsync(steps.data(), h->d_steps, (size_t)n * sizeof(long long),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(frac.data(), h->d_scratch + 7 * n, col, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // records 0..k exist; the last one is live unless the packet died in iteration k
+    long long acc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        off[(size_t)i] = acc;
+        const long long len = steps[(size_t)i] + (frac[(size_t)i] > 0.0 ? 1 : 0);
+        if (lengths_out) lengths_out[i] = len;
+        acc += len;
+    }
+    off[(size_t)n] = acc;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_offsets), &h->offsets_cap,
+                     ((size_t)n + 1) * sizeof(long long))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->d_offsets, off.data(), ((size_t)n + 1) * sizeof(long long),
+                          hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->rows_total = acc;
+    h->rows_step = step; h->rows_edge = outeredge; h->rows_n_iter = n_iter; h->rows_n = n;
+    *total_out = acc;
+    return NXC_OK;
+}
+
+int nxc_rows_fetch(nxc_handle *h, double *rows_out)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    const int64_t n = h->n_packets;
+    if (h->rows_total < 0 || h->rows_n != n)
+        return fail(NXC_ERR_STATE, "nxc_rows_fetch needs a preceding nxc_integrate_const_rows");
+    const long long total = h->rows_total;
+    h->rows_total = -1;
+    if (total == 0) return NXC_OK;
+    if (!rows_out) return fail(NXC_ERR_ARG, "rows_out is null");
+    const size_t bytes = (size_t)9 * (size_t)total * sizeof(double);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (bytes > free_b)
+        return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
+                                 "per call (the reference chunks too, Input.py:219-222)");
+    if (h->have_bodies) {
+        if (h->have_bounce)
+            return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
+        if ((rc = upload_moon_table(h, h->rows_step, h->rows_n_iter))) return rc;
+    }
+    double *d_rows = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rows), bytes));
+    if ((rc = upload_step(h, h->rows_step))) { (void)hipFree(d_rows); return rc; }
+    hipError_t e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
+    const size_t lds = h->force_bytes;
+    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
+    const double edge2 = sqrt_threshold(h->rows_edge);
+    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) {
+#define NXC_LAUNCH_ROWS(BOUNCE, NBODY)                                                          \
+    do {                                                                                        \
+        auto kernel = k_const_rows<BOUNCE, NBODY>;                                              \
+        rc = prep_kernel(kernel, lds);                                                          \
+        if (!rc)                                                                                \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F,       \
+                               h->d_blob, (int64_t)lds, n, h->d_packets, h->first_id,           \
+                               h->rows_n_iter, edge2, h->d_offsets, total, d_rows, h->d_ctr,    \
+                               NBODY ? h->d_moonpos : (const double *)nullptr);                 \
+    } while (0)
+        if (h->have_bodies) NXC_LAUNCH_ROWS(false, true);
+        else if (h->have_bounce) NXC_LAUNCH_ROWS(true, false);
+        else NXC_LAUNCH_ROWS(false, false);
+#undef NXC_LAUNCH_ROWS
+        if (!rc) e = hipGetLastError();
+    }
+    if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess && !rc) {
+        h->timed = true;
+        e = hipMemcpyAsync(rows_out, d_rows, bytes, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_rows);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
     return NXC_OK;
 }
 

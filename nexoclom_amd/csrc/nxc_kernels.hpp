@@ -172,6 +172,67 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lock-step driver writing only the live records (frac > 0), packet-major: row offsets[i] + k of
+// rows[9][total] is packet i after k iterations; column 8 is lossfrac (Output.py:420-421).
+template <bool BOUNCE, bool NBODY>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_const_rows(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
+             const double *__restrict__ soa0, int64_t first_id, int64_t n_iter, double edge2,
+             const long long *__restrict__ offsets, long long total, double *__restrict__ rows,
+             DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos)
+{
+    stage_tables(blob, stage_bytes);
+    const LutView T = lut_view(F.tab);
+    unsigned long long my_steps = 0, my_overrun = 0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double s[8], d[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) s[c] = soa0[c * n + i];
+        const long long off = offsets[i], len = offsets[i + 1] - off;
+        double lossfrac = 0.0;
+        long long k = 0;
+        int nbounce = 0;
+        bool alive = s[7] > 0.0;
+        if (alive) {
+            if (len > 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) rows[(long long)c * total + off] = s[c];
+                rows[8ll * total + off] = 0.0;
+            } else {
+                my_overrun++;
+            }
+        }
+        while (alive && k < n_iter) {
+            const double before = s[7];
+            if (NBODY) {
+                const BodyK *Bd = &lds_header().Bd;
+                const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
+                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+            } else {
+                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
+                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
+            }
+            k++; my_steps++;
+            lossfrac = (lossfrac + before) - s[7];
+            alive = s[7] > 0.0;
+            if (alive) {
+                if (k < len) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) rows[(long long)c * total + off + k] = s[c];
+                    rows[8ll * total + off + k] = lossfrac;
+                } else {
+                    my_overrun++;       // the two passes disagree: reported, never written
+                }
+            }
+        }
+    }
+    flush_counter(&ctr->particle_steps, my_steps);
+    flush_counter(&ctr->unfinished, my_overrun);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-level packet queue.  A wave claims NXC_CHUNK consecutive packet indices with one atomicAdd
 // on the global head and immediately copies their 8 state columns into its own LDS staging block
 // (coalesced: lane l loads packet base+l).  Lanes whose packet has died are then served from that

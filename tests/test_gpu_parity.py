@@ -191,3 +191,48 @@ def test_rccl_single_rank_allreduce(ctx, coracle):
     ctx.comm_destroy()
     assert np.array_equal(image0, image1) and np.array_equal(counts0, counts1)
     assert counts0.sum() > 0
+
+
+@pytest.mark.parametrize('bounce', [False, True])
+def test_compact_rows_equal_the_filtered_dense_trajectory(ctx, coracle, bounce):
+    """nxc_integrate_const_rows/nxc_rows_fetch == the frac > 0 records of the dense trajectory in
+    packet-major order (what Output.save() keeps, Output.py:523-524), bit for bit, with lossfrac
+    accumulated in the reference's association (Output.py:420-421)."""
+    f = H.mercury_forces('Na', 1.3)
+    endtime, step = 6000., 30.
+    n = 3000
+    X0 = H.sample_x0(n, 21, endtime)
+    X0[::17, 7] = 0.0                                    # packets that start dead: no rows
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    H.set_ctx_forces(ctx, f)
+    if bounce:
+        from nexoclom_amd.surface import SurfaceInteraction
+        import types
+        sint = types.SimpleNamespace(sticktype='constant', stickcoef=0.4, accomfactor=0.0)
+        cfg = dict(GM=f.GM, unit_km=f.R_km, accomfactor=0.0, stickcoef=0.4, A=(0., 0., 0.), t0=100.,
+                   t1=600., temp_dependent=False, tx=np.zeros(8), ty=np.zeros(8), coef=np.zeros(16),
+                   seed=77)
+        ctx.set_bounce(cfg)
+    try:
+        ctx.upload_packets(X0)
+        dense = ctx.integrate_const(step, n_iter, 6.0, nrec=nsteps)['traj']      # (8, nsteps, N)
+        ctx.upload_packets(X0)
+        res = ctx.integrate_const_rows(step, n_iter, 6.0)
+        assert ctx.counters()['unfinished'] == 0
+    finally:
+        ctx.set_bounce(None)
+    frac = dense[7].T                                                            # (N, nsteps)
+    live = frac > 0
+    assert np.array_equal(res['lengths'], live.sum(1))
+    # live records are a prefix of each packet's step axis
+    assert np.array_equal(live, np.arange(nsteps)[None, :] < res['lengths'][:, None])
+    for c in range(8):
+        assert np.array_equal(res['rows'][c], dense[c].T[live])
+    lossfrac = np.zeros_like(frac)
+    for ct in range(1, nsteps):
+        act = frac[:, ct-1] > 0
+        lossfrac[act, ct] = (lossfrac[act, ct-1] + frac[act, ct-1]) - frac[act, ct]
+    assert np.array_equal(res['rows'][8], lossfrac[live])
+    if not bounce:
+        c = coracle.integrate_const(f, X0, step, n_iter, 6.0, nrec=nsteps)
+        assert np.array_equal(dense, c['traj'])

@@ -1,0 +1,27 @@
+"""Where the time goes in the reference-style two-stage flow (Input.run with materialised
+trajectories -> catalogue -> ModelImage from the catalogue) for one reference-sized chunk."""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, '.')
+import nexoclom_amd
+from nexoclom_amd import Input, ModelImage, hip_api
+from nexoclom_amd.Output import Output
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 80467
+infile = os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles', 'Na.mercury.bench.input')
+inputs = Input(infile)
+ctx = hip_api.Context(0)
+tmp = tempfile.mkdtemp(dir='gpurun_out')
+for savepath in (None, tmp):
+    inputs._catalogue.clear()
+    inputs.savepath = savepath
+    t0 = time.time()
+    out = Output(inputs, n, seed=1, context=ctx, save=False)
+    t1 = time.time()
+    out.save()
+    t2 = time.time()
+    img = ModelImage(inputs, {'quantity': 'radiance', 'dims': '512,512'}, context=ctx)
+    t3 = time.time()
+    print(f'n={n} savepath={bool(savepath)}: Output(integrate+frame) {t1-t0:.2f}s '
+          f'(kernel {0:.0f}) save {t2-t1:.2f}s ModelImage(catalogue) {t3-t2:.2f}s rows={len(out.X)}', flush=True)
+import shutil; shutil.rmtree(tmp)
