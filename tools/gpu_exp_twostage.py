@@ -25,3 +25,15 @@ for savepath in (None, tmp):
     print(f'n={n} savepath={bool(savepath)}: Output(integrate+frame) {t1-t0:.2f}s '
           f'(kernel {0:.0f}) save {t2-t1:.2f}s ModelImage(catalogue) {t3-t2:.2f}s rows={len(out.X)}', flush=True)
 import shutil; shutil.rmtree(tmp)
+
+# the reference's own user flow at 1e6 packets: Input.run (chunked like Input.py:219-222, every
+# chunk catalogued with its trajectory) then Input.produce_image
+inputs = Input(infile)
+t0 = time.time()
+inputs.run(1e6, seed=7)
+t1 = time.time()
+img = inputs.produce_image({'quantity': 'radiance', 'dims': '512,512'})
+t2 = time.time()
+rows = sum(len(o.X) for o in inputs._catalogue)
+print(f'Input.run(1e6): {t1-t0:.1f}s in {len(inputs._catalogue)} chunks, {rows:.3e} stored rows; '
+      f'produce_image {t2-t1:.1f}s', flush=True)
