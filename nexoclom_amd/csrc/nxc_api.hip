@@ -31,6 +31,21 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+// No C++ exception may cross the C ABI: entry points that allocate on the host run inside this.
+template <class F>
+int guarded(F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(NXC_ERR_ARG, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(NXC_ERR_ARG, std::string("unexpected C++ exception: ") + e.what());
+    } catch (...) {
+        return fail(NXC_ERR_ARG, "unexpected C++ exception");
+    }
+}
+
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -462,6 +477,7 @@ int nxc_device_count(int *count)
 
 int nxc_create(int device, nxc_handle **out)
 {
+    return guarded([&]() -> int {
     if (!out) return fail(NXC_ERR_ARG, "out is null");
     *out = nullptr;
     int n = 0;
@@ -490,6 +506,7 @@ int nxc_create(int device, nxc_handle **out)
     }
     *out = h;
     return NXC_OK;
+    });
 }
 
 int nxc_destroy(nxc_handle *h)
@@ -526,6 +543,7 @@ int nxc_synchronize(nxc_handle *h)
 
 int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
 {
+    return guarded([&]() -> int {
     if (!h || !f) return fail(NXC_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
     PackedLut lut;
@@ -557,10 +575,12 @@ int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
     h->F.loss = f->lifetime > 0 ? LOSS_LIFETIME : (f->has_photo ? LOSS_PHOTO : LOSS_NONE);
     h->have_forces = true;
     return upload_blob(h);
+    });
 }
 
 int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
 {
+    return guarded([&]() -> int {
     if (!h || !d) return fail(NXC_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
     if (d->nx < 1 || d->nz < 1 || d->nx > 32768 || d->nz > 32768 || !d->xedges || !d->zedges)
@@ -619,10 +639,12 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     int rc = upload_blob(h);
     if (rc) return rc;
     return nxc_image_clear(h);
+    });
 }
 
 int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d)
 {
+    return guarded([&]() -> int {
     if (!h) return fail(NXC_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     if (!d) {                       // back to perfect sticking
@@ -651,10 +673,12 @@ int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d)
                               hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d)
 {
+    return guarded([&]() -> int {
     if (!h) return fail(NXC_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     BodyK &K = h->header.Bd;
@@ -693,6 +717,7 @@ int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d)
                               hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_set_first_index(nxc_handle *h, int64_t first_index)
@@ -756,6 +781,7 @@ int nxc_last_kernel_ms(nxc_handle *h, float *ms)
 int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const double *z,
               const double *vy, double *ax, double *ay, double *az, double *ioniz)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     if (n < 0 || (n && (!x || !y || !z || !vy || !ax || !ay || !az || !ioniz)))
@@ -779,11 +805,13 @@ int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const 
         HIPCHK(hipMemcpyAsync(dst[c], d + (4 + c) * n, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *hstep,
                  double *soa_out, double *delta_out)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     if (n < 0 || (n && (!soa_in || !hstep || !soa_out))) return fail(NXC_ERR_ARG, "bad arguments");
@@ -813,10 +841,12 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
         HIPCHK(hipMemcpyAsync(delta_out, d_delta, 8 * col, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
 {
+    return guarded([&]() -> int {
     if (!h || n < 0 || (n && !soa0)) return fail(NXC_ERR_ARG, "bad arguments");
     HIPCHK(hipSetDevice(h->device));
     const size_t bytes = (size_t)8 * n * sizeof(double);
@@ -864,6 +894,7 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     h->first_id = 0;
     h->rows_total = -1;
     return NXC_OK;
+    });
 }
 
 // Device-side queue order (the same counting sort nxc_packets_upload does on the host).
@@ -900,6 +931,7 @@ static int order_on_device(nxc_handle *h, double k2max)
 
 int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out)
 {
+    return guarded([&]() -> int {
     if (!h || !d || n < 1) return fail(NXC_ERR_ARG, "bad arguments");
     if (d->speed_type < 0 || d->speed_type > 1 || d->angular_type < 0 || d->angular_type > 1 ||
         !(d->unit_km > 0) || !(d->exobase > 0))
@@ -929,11 +961,13 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     if (soa_out) HIPCHK(hipMemcpyAsync(soa_out, h->d_packets, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     if (h->n_packets < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
@@ -941,12 +975,14 @@ int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double
     const bool image = (flags & NXC_RUN_IMAGE) != 0;
     if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
     return launch_const(h, step, n_iter, outeredge, image, nullptr, nullptr);
+    });
 }
 
 int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                         uint32_t flags, double *traj_out, int64_t nrec, double *final_out,
                         int64_t *steps_out)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     const int64_t n = h->n_packets;
@@ -1022,11 +1058,13 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
                               hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                              int64_t *lengths_out, int64_t *total_out)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     const int64_t n = h->n_packets;
@@ -1064,10 +1102,12 @@ int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double 
     h->rows_step = step; h->rows_edge = outeredge; h->rows_n_iter = n_iter; h->rows_n = n;
     *total_out = acc;
     return NXC_OK;
+    });
 }
 
 int nxc_rows_fetch(nxc_handle *h, double *rows_out)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     const int64_t n = h->n_packets;
@@ -1123,11 +1163,13 @@ int nxc_rows_fetch(nxc_handle *h, double *rows_out)
     if (rc) return rc;
     if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
     return NXC_OK;
+    });
 }
 
 int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,
                       double *final_out, double *hstore_out)
 {
+    return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
     const int64_t n = h->n_packets;
@@ -1156,11 +1198,13 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
         HIPCHK(hipMemcpyAsync(hstore_out, d_hs, col, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
                          const double *z, const double *vy, const double *frac)
 {
+    return guarded([&]() -> int {
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     HIPCHK(hipSetDevice(h->device));
     if (p < 0 || (p && (!x || !y || !z || !vy || !frac))) return fail(NXC_ERR_ARG, "bad arguments");
@@ -1182,6 +1226,7 @@ int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double
     if ((rc = end_timed(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
@@ -1190,6 +1235,7 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
                        int64_t n_index, double *radiance, int64_t *npackets, uint8_t *included,
                        int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
 {
+    return guarded([&]() -> int {
     if (!h || !d || S < 1 || P < 0 || !sc || !radiance || !npackets ||
         (P && (!x || !y || !z || !vy || !frac)))
         return fail(NXC_ERR_ARG, "bad arguments");
@@ -1284,6 +1330,7 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
                          hipMemcpyDeviceToHost));
     }
     return NXC_OK;
+    });
 }
 
 // ---- RCCL -------------------------------------------------------------------------------------
@@ -1362,6 +1409,7 @@ int nxc_barrier(nxc_handle *h)
 int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const double *in2,
                    double *out)
 {
+    return guarded([&]() -> int {
     if (!h || n < 0 || (n && (!in || !out)) || which < 0 || which > 4 || (which == 4 && !in2))
         return fail(NXC_ERR_ARG, "bad arguments");
     HIPCHK(hipSetDevice(h->device));
@@ -1378,6 +1426,7 @@ int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const 
     HIPCHK(hipMemcpyAsync(out, d + 2 * n, col, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
+    });
 }
 
 }  // extern "C"

@@ -189,9 +189,11 @@ NXC_DEV void bodies_eval(const BodyK &Bd, const double *__restrict__ mp, double 
         const double dx = x - mp[2 * m], dy = y - mp[2 * m + 1];
         const double r3 = nxc_cube(nxc_sqrt((dx * dx + dy * dy) + z * z));
         const double g = Bd.gm[m];
-        ax += nxc_div(g * dx, r3);
-        ay += nxc_div(g * dy, r3);
-        az += nxc_div(g * z, r3);
+        double qx, qy, qz;
+        nxc_div3(g * dx, g * dy, g * z, r3, qx, qy, qz);
+        ax += qx;
+        ay += qy;
+        az += qz;
     }
     if (Bd.chx_on) {
         const double rho = nxc_sqrt(x * x + y * y);

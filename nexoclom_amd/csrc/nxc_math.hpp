@@ -90,6 +90,21 @@ NXC_DEV double nxc_div(double n, double d)
     return nxc_div_seeded(n, d, nxc_recip_seed(d));
 }
 
+// Three quotients by one divisor, each equal to nxc_div's (one refined reciprocal serves all).
+NXC_DEV void nxc_div3(double n0, double n1, double n2, double d, double &q0, double &q1, double &q2)
+{
+    const bool ok = nxc_mid_range(d) && (nxc_mid_range(n0) || n0 == 0.0) &&
+                    (nxc_mid_range(n1) || n1 == 0.0) && (nxc_mid_range(n2) || n2 == 0.0);
+    if (!ok) {
+        q0 = n0 / d; q1 = n1 / d; q2 = n2 / d;
+        return;
+    }
+    const double y = nxc_recip_seed(d);
+    q0 = nxc_div_seeded(n0, d, y);
+    q1 = nxc_div_seeded(n1, d, y);
+    q2 = nxc_div_seeded(n2, d, y);
+}
+
 NXC_DEV double nxc_cube(double r)
 {
     double sq = r * r;
