@@ -158,10 +158,28 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = ALGO_BYTES_PER_PARTICLE_STEP*ctr['particle_steps']/(k_ms*1e-3)/1e9
         traffic = None
+        secondary = None
         tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get('k_const_fused_bytes_per_launch')
+                prof = json.load(open(tfile))
+                traffic = prof.get('k_const_fused_bytes_per_launch')
+                # the ceilings that actually bind this kernel, from the committed PMC profile:
+                # fp64 VALU issue (one wave64 fp64 instruction per 4 cycles per SIMD) and the
+                # memory-side scattered-atomic request rate (tools/ubench_atomics.hip)
+                cus = 256
+                insts = prof.get('k_const_fused_valu_wave_insts_per_launch')
+                atoms = prof.get('k_const_fused_atomic_requests_per_launch')
+                if insts and atoms:
+                    valu_floor_ms = insts/(cus*4*2.4e9/4)*1e3
+                    atomic_floor_ms = atoms/2.4e10*1e3
+                    secondary = {'valu_wave_insts_per_launch': insts,
+                                 'valu_issue_floor_ms': valu_floor_ms,
+                                 'valu_issue_frac': valu_floor_ms/k_ms,
+                                 'atomic_requests_per_launch': atoms,
+                                 'atomic_floor_ms': atomic_floor_ms,
+                                 'atomic_frac': atomic_floor_ms/k_ms,
+                                 'source': 'profiles/' + str(prof.get('tag', '')) + '_pmc.json'}
             except Exception:
                 traffic = None
         line = {
@@ -183,6 +201,7 @@ def main():
                          'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'k_const_fused<IMAGE>', 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_particle_step': ALGO_BYTES_PER_PARTICLE_STEP,
+                         'binding_ceilings': secondary,
                          'note': 'fused persistent kernel keeps packet state in registers: real '
                                  'HBM traffic is far below the algorithmic figure; the binding '
                                  'resource is fp64 VALU issue (see DESIGN.md)'},

@@ -43,6 +43,11 @@ if dom:
         traffic = {'k_const_fused_bytes_per_launch': fetch + write, 'fetch_bytes_corrected': fetch,
                    'write_bytes': write, 'tag': tag,
                    'note': 'FETCH_SIZE x2 (gfx950 half-count of wide reads), KiB units x1024'}
+        if 'SQ_INSTS_VALU' in s:
+            traffic['k_const_fused_valu_wave_insts_per_launch'] = s['SQ_INSTS_VALU']['mean_per_launch']
+        if 'TCC_EA0_ATOMIC_sum' in s:
+            traffic['k_const_fused_atomic_requests_per_launch'] = \
+                s['TCC_EA0_ATOMIC_sum']['mean_per_launch']
         json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print(json.dumps({'kernels': list(summary), 'traffic': traffic}, indent=1))
 for k, d in summary.items():
