@@ -316,24 +316,20 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     WaveQueue q;
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
-    bool has = false;
+    bool has = false, fresh = false;
     long long id = -1, k = 0;
     int nbounce = 0;
     double s[8], d[8];
+    // Per lane: a packet taken from the queue spends its first trip through the loop only being
+    // binned (record 0), every later trip advancing one step and being binned again, so that the
+    // step and the image code each appear once and run with (nearly) full waves.  A lane that is
+    // neither fresh nor free holds a live packet with k < n_iter.
     for (;;) {
         const long long got = q.refill(!has, &ctr->queue_head, n, soa0, order, stage_off, s);
-        if (got >= 0) {
-            id = got; k = 0; has = true; nbounce = 0;
-            if (IMAGE && s[7] > 0.0) {
-                my_samples++;
-                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                          my_nonfinite, acc);
-            }
-        }
+        if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
         if (__ballot(has) == 0) break;
         if (has) {
-            bool done = !(s[7] > 0.0) || k >= n_iter;
-            if (!done) {
+            if (!fresh) {
                 if (NBODY) {
                     const BodyK *Bd = &lds_header().Bd;
                     const double *mp = moon_pos + k * (12 * Bd->n_moons);
@@ -344,18 +340,15 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                     apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
                 }
                 k++; my_steps++;
-                if (s[7] > 0.0) {
-                    if (IMAGE) {
-                        my_samples++;
-                        my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image,
-                                                  counts, my_nonfinite, acc);
-                    }
-                    done = k >= n_iter;
-                } else {
-                    done = true;
-                }
             }
-            if (done) {
+            fresh = false;
+            const bool live = s[7] > 0.0;
+            if (IMAGE && live) {
+                my_samples++;
+                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image,
+                                          counts, my_nonfinite, acc);
+            }
+            if (!live || k >= n_iter) {
                 if (final_out) {
 #pragma unroll
                     for (int c = 0; c < 8; c++) final_out[c * n + id] = s[c];
