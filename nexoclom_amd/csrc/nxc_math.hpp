@@ -114,6 +114,11 @@ NXC_DEV double nxc_cube(double r)
     return cu + (cu_lo + sq_lo * r);
 }
 
+// fdlibm's exp with its three argument ranges (|x| <= ln2/2: no reduction; < 1.5 ln2: k = +-1;
+// else k from the quotient) folded into one instruction stream: lanes of a wave hold fractions
+// on both sides of every threshold, so separate branches would all be executed anyway.  With
+// k = 0 the reduced path gives the no-reduction result bit for bit: hi = x, lo = +0, and
+// (0 - q/(2-c)) - x == q/(c-2) - x because c-2 == -(2-c) and division is sign-symmetric.
 NXC_DEV double nxc_exp(double x)
 {
     constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -124,25 +129,18 @@ NXC_DEV double nxc_exp(double x)
     if (x != x) return x;
     if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
     if (x < -7.45133219101941108420e+02) return 0.0;
-    double ax = __builtin_fabs(x), hi = 0.0, lo = 0.0;
-    int k = 0;
-    if (ax > 0.34657359027997264) {
-        if (ax < 1.0397207708399179) {
-            k = x < 0 ? -1 : 1;
-        } else {
-            k = (int)(INV_LN2 * x + (x < 0 ? -0.5 : 0.5));
-        }
-        hi = x - (double)k * LN2_HI;
-        lo = (double)k * LN2_LO;
-        x = hi - lo;
-    } else if (ax < 3.725290298461914e-09) {
-        return 1.0 + x;
-    }
-    double t = x * x;
-    double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-    // |x| >= 2^-28 here and c = x(1 - ...) so both quotients have mid-range operands
-    if (k == 0) return 1.0 - (nxc_div_mid(x * c, c - 2.0) - x);
-    double y = 1.0 - ((lo - nxc_div_mid(x * c, 2.0 - c)) - hi);
+    const double ax = __builtin_fabs(x);
+    if (ax < 3.725290298461914e-09) return 1.0 + x;
+    const int kq = (int)(INV_LN2 * x + (x < 0 ? -0.5 : 0.5));
+    const int k1 = x < 0 ? -1 : 1;
+    const int k = ax > 0.34657359027997264 ? (ax < 1.0397207708399179 ? k1 : kq) : 0;
+    const double hi = x - (double)k * LN2_HI;
+    const double lo = (double)k * LN2_LO;
+    x = hi - lo;
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    // |x| >= 2^-28 here and c = x(1 - ...) so the quotient has mid-range operands
+    const double y = 1.0 - ((lo - nxc_div_mid(x * c, 2.0 - c)) - hi);
     if (k >= -1021)
         return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
     return __longlong_as_double(__double_as_longlong(y) + ((long long)(k + 1000) << 52))
@@ -182,12 +180,12 @@ NXC_DEV double nxc_log(double x)
     double R = t2 + t1;
     i = hx - 0x6147a;
     int j = 0x6b851 - hx;
-    if ((i | j) > 0) {
-        double hfsq = 0.5 * f * f;
-        return k == 0 ? f - (hfsq - s * (hfsq + R))
-                      : dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
-    }
-    return k == 0 ? f - s * (f - R) : dk * LN2_HI - ((s * (f - R) - dk * LN2_LO) - f);
+    // Both tails of fdlibm, selected per lane; its k == 0 forms are the k != 0 ones with dk = +0
+    // (0 - ((a - (p + 0)) - f) == f - (a - p) bit for bit, zero results included).
+    const double hfsq = 0.5 * f * f;
+    const double tail_a = (hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f;
+    const double tail_b = (s * (f - R) - dk * LN2_LO) - f;
+    return dk * LN2_HI - ((i | j) > 0 ? tail_a : tail_b);
 }
 
 NXC_DEV double nxc_pow_m025(double e) { return nxc_div(1.0, nxc_sqrt(nxc_sqrt(e))); }

@@ -37,6 +37,33 @@ def test_device_math_is_ieee_exact(ctx, coracle):
     assert np.array_equal(ctx.math('exp', e), coracle.math('exp', e))
     fr = np.concatenate([rng.uniform(1e-10, 1, 400000), 10**rng.uniform(-12, 3, 1000)])
     assert np.array_equal(ctx.math('log', fr), coracle.math('log', fr))
+    # the device exp/log fold fdlibm's argument ranges into one instruction stream: every range,
+    # both signs, and the neighbourhood (+-64 ulp) of every range threshold
+    def around(v, n=64):
+        out = [v]
+        lo = hi = v
+        for _ in range(n):
+            lo, hi = np.nextafter(lo, -np.inf), np.nextafter(hi, np.inf)
+            out += [lo, hi]
+        return np.array(out)
+    e = np.concatenate([rng.uniform(-0.4, 0.4, 200000), rng.uniform(-1.2, 1.2, 200000),
+                        rng.uniform(-745.5, 710, 200000), -rng.uniform(700, 746, 20000),
+                        rng.choice([-1., 1.], 50000)*10**rng.uniform(-14, 0, 50000),
+                        np.array([0.0, -0.0, 709.782712893384, -745.1332191019411])] +
+                       [sgn*around(t) for t in (0.34657359027997264, 1.0397207708399179,
+                                                3.725290298461914e-09, 0.6931471805599453)
+                        for sgn in (-1., 1.)])
+    with np.errstate(over='ignore', under='ignore'):
+        assert np.array_equal(ctx.math('exp', e), coracle.math('exp', e))
+    mant = lambda h: np.frombuffer(np.array([(0x3ff00000 | h) << 32], dtype=np.uint64).tobytes(),
+                                   dtype=np.float64)[0]
+    lg = np.concatenate([1 + rng.choice([-1., 1.], 100000)*10**rng.uniform(-16, -0.5, 100000),
+                         10**rng.uniform(-320, 300, 100000), rng.uniform(0.25, 4, 400000),
+                         np.array([1.0, 0.5, 2.0, 5e-324, 2.2250738585072014e-308])] +
+                        [sc*around(mant(h)) for h in (0x6147a, 0x6b851, 0x6a09f, 0x00002, 0xffffd)
+                         for sc in (0.25, 0.5, 1.0, 2.0)])
+    lg = lg[lg > 0]
+    assert np.array_equal(ctx.math('log', lg), coracle.math('log', lg))
 
 
 @pytest.mark.parametrize('gravity,radpres,lifetime', [
