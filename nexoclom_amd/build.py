@@ -5,6 +5,11 @@ GPU; the resulting .so is git-ignored but travels to the GPU box with the snapsh
 
 Flags that matter for parity: ``-ffp-contract=off -fno-fast-math`` (one rounding per fp64
 operation, as NumPy) and ``-munsafe-fp-atomics`` (hardware global_atomic_add_f64 for the image).
+Flag that matters for speed: ``-mllvm -disable-machine-licm``.  Machine LICM hoists the 64-bit
+constants of the exp/log/division code out of the persistent loop into scalar registers, which
+then spill (30-60 SGPRs reloaded with v_readlane inside the loop); without it the fused kernel has
+no spills and 13 fewer VGPRs.  ``-DNXC_EXPERIMENT_KNOBS`` (tools/ only) compiles the timing
+switches of the image path in.
 """
 import os
 import shutil
@@ -19,8 +24,10 @@ DEPS.append(os.path.join(os.path.dirname(HERE), 'include', 'nexoclom_hip.h'))
 OUT = os.path.join(HERE, 'lib', 'libnexoclom_hip.so')
 
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-fast-math',
-         '-munsafe-fp-atomics', '-fPIC', '-shared', '-std=c++17', '-Wall',
-         '-Wno-unused-function']
+         '-munsafe-fp-atomics', '-mllvm', '-disable-machine-licm', '-fPIC', '-shared',
+         '-std=c++17', '-Wall', '-Wno-unused-function']
+if os.environ.get('NXC_EXPERIMENT_KNOBS'):
+    FLAGS.append('-DNXC_EXPERIMENT_KNOBS')
 
 
 def hipcc():

@@ -602,7 +602,9 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     G.quantity = d->quantity;
     G.n_lines = nl;
     G.downcast_f32 = d->downcast_f32 ? 1 : 0;
+#ifdef NXC_EXPERIMENT_KNOBS
     if (const char *dbg = std::getenv("NXC_DEBUG_IMAGE")) G.dbg = std::atoi(dbg);
+#endif
     G.nx = (int)d->nx;
     G.nz = (int)d->nz;
     for (int l = 0; l < nl; l++) {

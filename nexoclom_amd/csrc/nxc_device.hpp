@@ -325,17 +325,40 @@ struct BounceK {
     const double *tx, *ty, *coef;
 };
 
+// Kernel arguments the persistent loop touches only rarely (a chunk claim per 64 packets, a final
+// state per packet).  The kernel copies them here before its loop and reads them back at the
+// point of use, so that they do not occupy scalar registers across the whole loop.
+struct LoopK {
+    const double *soa0;
+    const unsigned *order;
+    double *final_out;
+    long long *steps_out;
+    unsigned long long *head;
+    long long n;
+};
+// Refined reciprocals of the two launch-constant divisors of the weight (1e6, Apix), computed once
+// per workgroup; read from LDS by the samples that fall inside the image.
+struct WeightK {
+    double rs_1e6, rs_apix;
+};
+
 struct LdsHeader {
     ImageK G;
     StepW W;
     BounceK B;
     BodyK Bd;
+    LoopK L;
+    WeightK Wt;
 };
 constexpr int NXC_HEADER_BYTES = (int)((sizeof(LdsHeader) + 31) & ~size_t(31));
 
 NXC_DEV const LdsHeader &lds_header()
 {
     return *reinterpret_cast<const LdsHeader *>(nxc_lds);
+}
+NXC_DEV LdsHeader &lds_header_rw()
+{
+    return *reinterpret_cast<LdsHeader *>(nxc_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,7 +545,7 @@ NXC_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // per thread before the step loop (the compiler cannot hoist LDS loads over the loop's LDS
 // stores).  The two refined reciprocals serve the per-sample divisions by 1e6 and by Apix.
 struct ImageRegs {
-    double vrplanet, rs_1e6, rs_apix, apix;
+    double vrplanet;
     double x_lo, x_hi, x_inv_step, z_lo, z_hi, z_inv_step;
     int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg;
 };
@@ -541,24 +564,28 @@ NXC_DEV ImageRegs image_regs(const ImageK &G)
 {
     ImageRegs R;
     R.vrplanet = G.vrplanet;
-    R.apix = G.apix_cm2;
-    R.rs_1e6 = nxc_recip_seed(1e6);
-    R.rs_apix = nxc_recip_seed(G.apix_cm2);
     R.xedges = (int)G.xedges_off; R.zedges = (int)G.zedges_off;
     R.nx = G.nx; R.nz = G.nz;
     R.x_lo = lds_f64(R.xedges); R.x_hi = lds_f64(R.xedges + 8 * R.nx);
     R.z_lo = lds_f64(R.zedges); R.z_hi = lds_f64(R.zedges + 8 * R.nz);
     R.x_inv_step = G.x_inv_step; R.z_inv_step = G.z_inv_step;
-    R.quantity = G.quantity; R.n_lines = G.n_lines; R.downcast = G.downcast_f32; R.dbg = G.dbg;
-    R.vrplanet = wave_uniform(R.vrplanet); R.apix = wave_uniform(R.apix);
-    R.rs_1e6 = wave_uniform(R.rs_1e6); R.rs_apix = wave_uniform(R.rs_apix);
+    R.quantity = G.quantity; R.n_lines = G.n_lines; R.downcast = G.downcast_f32;
+#ifdef NXC_EXPERIMENT_KNOBS     // tools/ timing experiments only: the product build has no such switch
+    R.dbg = G.dbg;
+#else
+    R.dbg = 0;
+#endif
+    R.vrplanet = wave_uniform(R.vrplanet);
     R.x_lo = wave_uniform(R.x_lo); R.x_hi = wave_uniform(R.x_hi);
     R.z_lo = wave_uniform(R.z_lo); R.z_hi = wave_uniform(R.z_hi);
     R.x_inv_step = wave_uniform(R.x_inv_step); R.z_inv_step = wave_uniform(R.z_inv_step);
     R.xedges = wave_uniform(R.xedges); R.zedges = wave_uniform(R.zedges);
     R.nx = wave_uniform(R.nx); R.nz = wave_uniform(R.nz);
     R.quantity = wave_uniform(R.quantity); R.n_lines = wave_uniform(R.n_lines);
-    R.downcast = wave_uniform(R.downcast); R.dbg = wave_uniform(R.dbg);
+    R.downcast = wave_uniform(R.downcast);
+#ifdef NXC_EXPERIMENT_KNOBS
+    R.dbg = wave_uniform(R.dbg);
+#endif
     return R;
 }
 
@@ -595,7 +622,7 @@ NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 // is bound by the chip's scattered-atomic rate, so every merged pair is time saved; the packet
 // counts stay exact and the weighted sum only changes its (already arbitrary) summation order.
 struct PixelAcc {
-    long long pix = -1;
+    int pix = -1;                 // nx*nz < 2^31 (checked by nxc_set_image)
     double w = 0.0;
     unsigned long long c = 0;
 
@@ -607,7 +634,7 @@ struct PixelAcc {
         }
         pix = -1; w = 0.0; c = 0;
     }
-    NXC_DEV void add(long long p, double wt, double *image, unsigned long long *counts, int dbg)
+    NXC_DEV void add(int p, double wt, double *image, unsigned long long *counts, int dbg)
     {
         if (p != pix) {
             flush(image, counts, dbg);
@@ -651,10 +678,10 @@ NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y
         for (int l = 1; l < 4; l++)
             if (l < R.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
         const double lit = sunlit(x, y, z) ? frac : frac * 0.0;
-        w = nxc_div_const(lit * gg, 1e6, R.rs_1e6);
+        w = nxc_div_const(lit * gg, 1e6, lds_header().Wt.rs_1e6);
     }
-    w = nxc_div_const(w, R.apix, R.rs_apix);                       // ModelImage.py:262
+    w = nxc_div_const(w, G.apix_cm2, lds_header().Wt.rs_apix);     // ModelImage.py:262
     if (!(__builtin_fabs(w) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;   // :170
-    acc.add((long long)ix * R.nz + iz, w, image, counts, R.dbg);
+    acc.add(ix * R.nz + iz, w, image, counts, R.dbg);
     return 1;
 }

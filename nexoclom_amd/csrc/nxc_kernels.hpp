@@ -31,13 +31,34 @@ constexpr int NXC_BLOCK_PERSIST = 768;
 constexpr int NXC_CHUNK = 64;       // packets claimed from the global queue per atomic (one per lane)
 constexpr int NXC_WAVE_STAGE_BYTES = NXC_CHUNK * 9 * 8;   // per-wave LDS staging: 8 columns + packet id
 
-// Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS.
+// Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS, then the
+// derived per-launch constants of the header.
 NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
 {
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(blob);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(nxc_lds);
     const int64_t words = bytes >> 3;
     for (int64_t w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LdsHeader &H = lds_header_rw();
+        H.Wt.rs_1e6 = nxc_recip_seed(1e6);
+        H.Wt.rs_apix = nxc_recip_seed(H.G.apix_cm2);
+    }
+    __syncthreads();
+}
+
+// stage_tables + the loop's rarely used kernel arguments parked in the LDS header (LoopK).
+NXC_DEV void stage_tables_and_args(const unsigned char *__restrict__ blob, int64_t bytes,
+                                   const double *soa0, const unsigned *order, double *final_out,
+                                   long long *steps_out, unsigned long long *head, long long n)
+{
+    stage_tables(blob, bytes);
+    if (threadIdx.x == 0) {
+        LoopK &L = lds_header_rw().L;
+        L.soa0 = soa0; L.order = order; L.final_out = final_out; L.steps_out = steps_out;
+        L.head = head; L.n = n;
+    }
     __syncthreads();
 }
 
@@ -249,9 +270,7 @@ struct WaveQueue {
     int c_pos = 0, c_cnt = 0;
     bool drained = false;
 
-    NXC_DEV long long refill(bool need, unsigned long long *head, long long n,
-                             const double *__restrict__ soa0, const unsigned *__restrict__ order,
-                             int stage_off, double (&s)[8])
+    NXC_DEV long long refill(bool need, int stage_off, double (&s)[8])
     {
         const unsigned long long mask = __ballot(need);
         long long mine = -1;
@@ -263,8 +282,12 @@ struct WaveQueue {
         int served = 0;
         while (served < want) {
             if (c_pos >= c_cnt) {
+                const LoopK &L = lds_header().L;
+                const long long n = L.n;
+                const double *__restrict__ soa0 = L.soa0;
+                const unsigned *__restrict__ order = L.order;
                 long long b = 0;
-                if (lane == 0) b = (long long)atomicAdd(head, (unsigned long long)NXC_CHUNK);
+                if (lane == 0) b = (long long)atomicAdd(L.head, (unsigned long long)NXC_CHUNK);
                 b = wave_bcast0(b);
                 if (b >= n) { drained = true; break; }
                 c_base = b;
@@ -308,7 +331,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr,
               const double *__restrict__ moon_pos = nullptr)
 {
-    stage_tables(blob, stage_bytes);
+    stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n);
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
@@ -325,7 +348,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     // step and the image code each appear once and run with (nearly) full waves.  A lane that is
     // neither fresh nor free holds a live packet with k < n_iter.
     for (;;) {
-        const long long got = q.refill(!has, &ctr->queue_head, n, soa0, order, stage_off, s);
+        const long long got = q.refill(!has, stage_off, s);
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
         if (__ballot(has) == 0) break;
         if (has) {
@@ -349,11 +372,13 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                                           counts, my_nonfinite, acc);
             }
             if (!live || k >= n_iter) {
-                if (final_out) {
+                const LoopK &L = lds_header().L;
+                if (double *fo = L.final_out) {
+                    const long long np = L.n;
 #pragma unroll
-                    for (int c = 0; c < 8; c++) final_out[c * n + id] = s[c];
+                    for (int c = 0; c < 8; c++) fo[c * np + id] = s[c];
                 }
-                if (steps_out) steps_out[id] = k;
+                if (long long *so = L.steps_out) so[id] = k;
                 has = false;
             }
         }
@@ -381,7 +406,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
       double *__restrict__ final_out, double *__restrict__ hstore_out,
       DevCounters *__restrict__ ctr)
 {
-    stage_tables(blob, stage_bytes);
+    stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, nullptr, &ctr->queue_head, n);
     const LutView T = lut_view(F.tab);
     const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
     unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
@@ -391,7 +416,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     long long id = -1, it = 0;
     double s[8], hs = 1000.0;
     for (;;) {
-        const long long got = q.refill(!has, &ctr->queue_head, n, soa0, order, stage_off, s);
+        const long long got = q.refill(!has, stage_off, s);
         if (got >= 0) {
             id = got; it = 0; hs = 1000.0; has = true;
         }
