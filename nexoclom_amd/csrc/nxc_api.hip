@@ -561,7 +561,9 @@ int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
     // 2 % at 4), so the two-row probe of lut_interp hits and the divergent walk mostly stays out
     // of the step loop; 16 measured slower again in the image kernel (LDS footprint).
     h->force_cells_per_node = 8;
+#ifdef NXC_EXPERIMENT_KNOBS
     if (const char *e = std::getenv("NXC_FORCE_CELLS")) h->force_cells_per_node = std::max(2, std::atoi(e));
+#endif
     rc = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
                   "nxc_forces radiation table", h->force_cells_per_node);
     if (rc) return rc;
