@@ -28,6 +28,7 @@ FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-fast-math',
          '-std=c++17', '-Wall', '-Wno-unused-function']
 if os.environ.get('NXC_EXPERIMENT_KNOBS'):
     FLAGS.append('-DNXC_EXPERIMENT_KNOBS')
+FLAGS += os.environ.get('NXC_EXTRA_FLAGS', '').split()      # experiments only
 
 
 def hipcc():

@@ -27,8 +27,15 @@ constexpr int NXC_BLOCK = 256;      // threads per workgroup of the flat kernels
 // The persistent kernels run ONE 12-wave workgroup per CU (3 waves per SIMD, <= 168 VGPRs): the
 // waves of a workgroup share a single LDS copy of the tables (~76 KB for Na with a 512^2 image),
 // which leaves room for the per-wave packet staging blocks inside the CU's 160 KB.
-constexpr int NXC_BLOCK_PERSIST = 768;
-constexpr int NXC_CHUNK = 64;       // packets claimed from the global queue per atomic (one per lane)
+#ifndef NXC_BLOCK_PERSIST_N          // overridable for occupancy experiments (tools/)
+#define NXC_BLOCK_PERSIST_N 768
+#endif
+#ifndef NXC_CHUNK_N
+#define NXC_CHUNK_N 64
+#endif
+constexpr int NXC_BLOCK_PERSIST = NXC_BLOCK_PERSIST_N;
+constexpr int NXC_CHUNK = NXC_CHUNK_N;   // packets claimed from the global queue per atomic (<= 64: one per lane)
+static_assert(NXC_CHUNK >= 1 && NXC_CHUNK <= 64, "a chunk is loaded by one wave");
 constexpr int NXC_WAVE_STAGE_BYTES = NXC_CHUNK * 9 * 8;   // per-wave LDS staging: 8 columns + packet id
 
 // Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS, then the
