@@ -441,14 +441,20 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                     rk5_step<true, false>(F, T, t, h, StepW{}, d);
                     my_steps++; it++;
                     const double fscale = resf + __builtin_fabs(t[7]) * resf;
+                    // max over the columns; a NaN quotient must not be dropped by fmax (the
+                    // reference asserts on non-finite errmax, Output.py:284 -- and would spin
+                    // forever on a row whose max() skipped the NaN)
                     double e = d[0];
+                    bool finite = true;
 #pragma unroll
-                    for (int c = 1; c <= 3; c++)
-                        e = __builtin_fmax(e, nxc_div(d[c], resx + __builtin_fabs(t[c]) * resx));
-#pragma unroll
-                    for (int c = 4; c <= 6; c++)
-                        e = __builtin_fmax(e, nxc_div(d[c], resv + __builtin_fabs(t[c]) * resv));
-                    e = __builtin_fmax(e, nxc_div(d[7], fscale));
+                    for (int c = 1; c <= 7; c++) {
+                        const double scale = c <= 3 ? resx + __builtin_fabs(t[c]) * resx
+                                           : c <= 6 ? resv + __builtin_fabs(t[c]) * resv : fscale;
+                        const double q = nxc_div(d[c], scale);
+                        finite = finite && (__builtin_fabs(q) <= 1.7976931348623157e308);
+                        e = __builtin_fmax(e, q);
+                    }
+                    if (!finite) e = __builtin_nan("");
                     if (!(__builtin_fabs(e) <= 1.7976931348623157e308)) { my_nonfinite++; done = true; }
                     else {
                         if (t[7] < 0.0 && e < 1.0) my_neg++;

@@ -420,9 +420,15 @@ int64_t ora_integrate_var(const ora_forces *f, int64_t n, const double *soa0, do
             work++; it++;
             double fr_scale = resf + fabs(t[7]) * resf;
             double e = d[0];                                   /* time column: 0 */
-            for (int c = 1; c <= 3; c++) e = fmax(e, d[c] / (resx + fabs(t[c]) * resx));
-            for (int c = 4; c <= 6; c++) e = fmax(e, d[c] / (resv + fabs(t[c]) * resv));
-            e = fmax(e, d[7] / fr_scale);
+            int finite = 1;     /* fmax would drop a NaN quotient; the assert (Output.py:284) must see it */
+            for (int c = 1; c <= 7; c++) {
+                double scale = c <= 3 ? resx + fabs(t[c]) * resx
+                             : c <= 6 ? resv + fabs(t[c]) * resv : fr_scale;
+                double q = d[c] / scale;
+                if (!isfinite(q)) finite = 0;
+                e = fmax(e, q);
+            }
+            if (!finite) e = NAN;
             if (!isfinite(e)) { nbad++; break; }
             if (t[7] < 0 && e < 1) nbad++;
             if ((t[7] - s[7] > fr_scale) && (e > 1)) e = 1.1;

@@ -135,3 +135,50 @@ def test_gravity_only_energy_at_scale(ctx):
     e0 = 0.5*np.sum(X0[:, 4:7]**2, axis=1) + f.GM/np.linalg.norm(X0[:, 1:4], axis=1)
     e1 = 0.5*np.sum(fin[:, 4:7]**2, axis=1) + f.GM/np.linalg.norm(fin[:, 1:4], axis=1)
     assert np.allclose(e1[alive], e0[alive], rtol=1e-6, atol=1e-14)
+
+
+def test_non_finite_inputs_raise_the_reference_assertions(ctx):
+    """The reference asserts on non-finite error estimates (Output.py:284) and weights
+    (ModelResult.py:170); on the device these are counters that the host turns back into the
+    same AssertionErrors."""
+    import contextlib
+    import io
+    import os
+    import nexoclom_amd
+    from nexoclom_amd import Input
+    from nexoclom_amd.Output import Output
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    X0 = H.sample_x0(256, 4, 3000.)
+    X0[7, 5] = np.nan                      # one packet with a NaN velocity component
+    X0[9, 1] = np.inf                      # one at infinity
+    # variable-step driver: non-finite errmax is counted, the other packets finish normally
+    Xv = X0.copy()
+    Xv[:, 0] = 2000.
+    ctx.upload_packets(Xv)
+    final, hs = ctx.integrate_var(1e-4, 20.)
+    ctr = ctx.counters()
+    assert ctr['nonfinite'] >= 2 and ctr['unfinished'] == 0
+    ok = np.ones(256, bool); ok[[7, 9]] = False
+    assert np.isfinite(final[ok]).all()
+    # fused image: the weight's finiteness check
+    im = H.image_setup(f, 'radiance', dims=(32, 32))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'])
+    ctx.upload_packets(X0)
+    ctx.integrate_const(30., 100, 20., image=True)
+    assert ctx.counters()['nonfinite'] >= 1
+    image, counts = ctx.image_download()
+    assert np.isfinite(image).all()        # the bad samples never reach a pixel
+    # and through the public API: the same AssertionError text as the reference
+    inputs = Input(os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles',
+                                'Na.mercury.bench.input'))
+    inputs.options.step_size = 0.
+    inputs.options.resolution = 1e-4
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = Output(inputs, 64, seed=2, integrate=False, save=False, context=ctx)
+        out.X = out.X0.drop(['longitude', 'latitude', 'local_time'], axis=1)
+        out.X['lossfrac'] = 0.0
+        out.X.loc[3, 'vx'] = np.nan
+        with pytest.raises(AssertionError, match='Infinite values of emax'):
+            out.variable_step_size_driver()
