@@ -355,7 +355,7 @@ class Context:
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             C.c_uint32(NXC_RUN_IMAGE if image else 0)))
 
-    def integrate_var(self, resolution, outeredge, max_steps=10**7):
+    def integrate_var(self, resolution, outeredge, max_steps=10**6):
         n = self.n_packets
         final = np.empty((8, n))
         hs = np.empty(n)
