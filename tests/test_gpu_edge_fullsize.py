@@ -182,3 +182,49 @@ def test_non_finite_inputs_raise_the_reference_assertions(ctx):
         out.X.loc[3, 'vx'] = np.nan
         with pytest.raises(AssertionError, match='Infinite values of emax'):
             out.variable_step_size_driver()
+
+
+def test_pathological_states_follow_the_oracle_bit_for_bit(ctx, coracle):
+    """Packets at the origin, at 1e-160 and 1e150 radii, with zero, tiny, >1 and negative
+    fractions, zero time and absurd velocities: the out-of-range fall-back paths of the device
+    arithmetic (full IEEE division / sqrt, exp/log specials) give the C oracle's bits, NaNs and
+    infinities included, and nothing spins or faults."""
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    base = H.sample_x0(64, 9, 3000.)
+    X0 = base.copy()
+    X0[0, 1:4] = 0.0
+    X0[1, 1:4] = [1e-160, -2e-160, 3e-161]
+    X0[2, 1:4] = [1e150, 1e150, -1e150]
+    X0[3, 1:4] = [3e102, 0, 0]
+    X0[4, 7] = 0.0
+    X0[5, 7] = 1e-300
+    X0[6, 7] = 2.0
+    X0[7, 7] = -0.5
+    X0[8, 0] = 0.0
+    X0[9, 4:7] = [1e10, -1e10, 1e10]
+    X0[10, 4:7] = 0.0
+    X0[11, 1:4] = [1.0, 0.0, 0.0]            # exactly on the surface, on rho = 1, y = 0
+    X0[11, 4:7] = 0.0
+    X0[12, 5] = 1e3                           # far outside the radiation table
+    X0[13, 5] = -1e3
+    X0[14, 7] = 1e-10                         # at the vanishing threshold
+    X0[15, 7] = np.nextafter(1e-10, 0)
+    n_iter = 40
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., n_iter, 1e30, nrec=n_iter + 1, want_final=True, want_steps=True)
+    c = coracle.integrate_const(f, X0, 30., n_iter, 1e30, nrec=n_iter + 1)
+    assert np.array_equal(g['steps'], c['steps'])
+    assert np.array_equal(g['traj'], c['traj'], equal_nan=True)
+    assert np.array_equal(g['final'], c['final'], equal_nan=True)
+    # the persistent kernel agrees with the lock-step one on them too
+    ctx.upload_packets(X0)
+    p = ctx.integrate_const(30., n_iter, 1e30, want_final=True, want_steps=True)
+    assert np.array_equal(p['steps'], c['steps'])
+    assert np.array_equal(p['final'], c['final'], equal_nan=True)
+    # single rk5 steps with per-packet step sizes spanning 1e-300 .. 1e300
+    hh = 10.0**np.linspace(-300, 300, 64)
+    r_g, d_g = ctx.rk5_step(X0, hh, want_delta=True)
+    with np.errstate(all='ignore'):
+        r_c, d_c = coracle.rk5(f, X0, hh, want_delta=True)
+    assert np.array_equal(r_g, r_c, equal_nan=True) and np.array_equal(d_g, d_c, equal_nan=True)
