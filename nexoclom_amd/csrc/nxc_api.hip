@@ -198,8 +198,7 @@ struct nxc_handle {
     size_t blob_cap = 0, force_bytes = 0, all_bytes = 0;
 
     // resident data
-    double *d_image = nullptr;
-    unsigned long long *d_counts = nullptr;
+    double *d_image = nullptr;       // interleaved {weight sum, packet count} per pixel, fp64
     size_t npix = 0;
     double *d_packets = nullptr;
     size_t packets_cap = 0;
@@ -400,8 +399,7 @@ int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, doubl
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
                        (int64_t)tables, h->n_packets, h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
-                       edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
-                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr,
+                       edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr, h->d_ctr,
                        NBODY ? h->d_moonpos : (const double *)nullptr);
     HIPCHK(hipGetLastError());
     return end_timed(h);
@@ -446,8 +444,7 @@ int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double 
     const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F, h->d_blob,
                        (int64_t)lds, n, h->d_packets, h->first_id, n_iter, edge2, d_traj, nrec,
-                       d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr,
-                       IMAGE ? h->d_counts : (unsigned long long *)nullptr, h->d_ctr,
+                       d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr, h->d_ctr,
                        NBODY ? h->d_moonpos : (const double *)nullptr);
     HIPCHK(hipGetLastError());
     return NXC_OK;
@@ -515,7 +512,7 @@ int nxc_destroy(nxc_handle *h)
     (void)hipSetDevice(h->device);
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_blob, h->d_image, h->d_counts, h->d_packets, h->d_ctr, h->d_scratch,
+    void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -634,10 +631,8 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     const size_t npix = (size_t)d->nx * (size_t)d->nz;
     if (npix != h->npix) {
         if (h->d_image) HIPCHK(hipFree(h->d_image));
-        if (h->d_counts) HIPCHK(hipFree(h->d_counts));
-        h->d_image = nullptr; h->d_counts = nullptr; h->npix = 0;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_image), npix * sizeof(double)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_counts), npix * sizeof(unsigned long long)));
+        h->d_image = nullptr; h->npix = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&h->d_image), 2 * npix * sizeof(double)));
         h->npix = npix;
     }
     int rc = upload_blob(h);
@@ -735,8 +730,7 @@ int nxc_image_clear(nxc_handle *h)
 {
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemsetAsync(h->d_image, 0, h->npix * sizeof(double), h->stream));
-    HIPCHK(hipMemsetAsync(h->d_counts, 0, h->npix * sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_image, 0, 2 * h->npix * sizeof(double), h->stream));
     return NXC_OK;
 }
 
@@ -744,14 +738,18 @@ int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
 {
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     HIPCHK(hipSetDevice(h->device));
-    if (image)
-        HIPCHK(hipMemcpyAsync(image, h->d_image, h->npix * sizeof(double), hipMemcpyDeviceToHost,
-                              h->stream));
-    if (counts)
-        HIPCHK(hipMemcpyAsync(counts, h->d_counts, h->npix * sizeof(uint64_t),
-                              hipMemcpyDeviceToHost, h->stream));
+    return guarded([&]() -> int {
+    // the device keeps {weight sum, count} interleaved in fp64 (see PixelAcc); split here
+    std::vector<double> both(2 * h->npix);
+    HIPCHK(hipMemcpyAsync(both.data(), h->d_image, 2 * h->npix * sizeof(double),
+                          hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (size_t q = 0; q < h->npix; q++) {
+        if (image) image[q] = both[2 * q];
+        if (counts) counts[q] = (uint64_t)both[2 * q + 1];      // integer-valued, < 2^53
+    }
     return NXC_OK;
+    });
 }
 
 int nxc_counters_get(nxc_handle *h, nxc_counters *out)
@@ -1225,7 +1223,7 @@ int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_image, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
                        h->stream, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
-                       d + 3 * p, d + 4 * p, h->d_image, h->d_counts, h->d_ctr);
+                       d + 3 * p, d + 4 * p, h->d_image, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1384,9 +1382,8 @@ int nxc_image_allreduce(nxc_handle *h)
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
-    NCCLCHK(g_rccl.AllReduce(h->d_image, h->d_image, h->npix, ncclFloat64, ncclSum, h->comm,
-                             h->stream));
-    NCCLCHK(g_rccl.AllReduce(h->d_counts, h->d_counts, h->npix, ncclUint64, ncclSum, h->comm,
+    // one collective: weights and (integer-valued fp64) counts are interleaved in one array
+    NCCLCHK(g_rccl.AllReduce(h->d_image, h->d_image, 2 * h->npix, ncclFloat64, ncclSum, h->comm,
                              h->stream));
     return NXC_OK;
 }

@@ -615,42 +615,68 @@ NXC_DEV int bin_index(double v, int edges, int n, double lo, double hi, double i
 
 NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 
-// Per-lane pending contribution to one pixel.  Consecutive records of a packet often fall into
-// the same pixel (a 30 s step moves a packet by about one pixel of a 512^2 image), so a lane
-// keeps summing weight and count while the pixel does not change and only then issues the two
-// global atomics (the hardware global_atomic_add_f64 and a 64-bit integer add).  The fused kernel
-// is bound by the chip's scattered-atomic rate, so every merged pair is time saved; the packet
-// counts stay exact and the weighted sum only changes its (already arbitrary) summation order.
+// Image accumulator = one interleaved fp64 array acc2[2*pix] = weight sum, acc2[2*pix + 1] = packet
+// count (integers are exact in fp64 up to 2^53), accumulated with global_atomic_add_f64.
+//
+// Atomics execute at the memory side, one request per 64-byte line touched by a wave instruction
+// (tools/ubench_atomics.hip: 24 G scattered lane-atomics/s, but 47 G/s when lanes l and l+32 add
+// to the two halves of one 16-byte record).  So a pixel's weight and count are added by two lanes
+// of the SAME instruction: in the first instruction lanes 0..31 add their own weight while lanes
+// 32..63 add the count of their partner lane (l - 32); the second instruction serves the upper
+// half's samples the other way round.  One request per flushed pixel instead of two.
+//
+// Each lane also keeps summing weight and count while its packet stays in one pixel and flushes
+// only when the pixel changes (a 30 s step moves a packet by about one 512^2 pixel).  The packet
+// counts stay exact; the weighted sum only changes its (already arbitrary) summation order.
+// put() and drain() are wave-cooperative: all 64 lanes must call them from uniform control flow.
 struct PixelAcc {
     int pix = -1;                 // nx*nz < 2^31 (checked by nxc_set_image)
     double w = 0.0;
-    unsigned long long c = 0;
+    unsigned c = 0;
 
-    NXC_DEV void flush(double *image, unsigned long long *counts, int dbg)
+    NXC_DEV void flush_pairs(bool need, double *__restrict__ acc2)
     {
-        if (pix >= 0 && dbg != 1) {
-            if (w != 0.0 && dbg != 3) unsafeAtomicAdd(&image[pix], w);
-            if (dbg != 2) atomicAdd(&counts[pix], c);
+        if (__ballot(need) == 0) return;
+        const int ppix = __shfl_xor(need ? pix : -1, 32, 64);     // partner lane's pending pixel
+        const unsigned pc = (unsigned)__shfl_xor((int)c, 32, 64);
+        const bool upper = (threadIdx.x & 32) != 0;
+        const bool own = need && w != 0.0;                         // a zero sum adds nothing
+        const bool partner = ppix >= 0;
+        {   // samples of lanes 0..31
+            const bool act = upper ? partner : own;
+            if (act)
+                unsafeAtomicAdd(&acc2[2ll * (upper ? ppix : pix) + (upper ? 1 : 0)],
+                                upper ? (double)pc : w);
         }
-        pix = -1; w = 0.0; c = 0;
+        {   // samples of lanes 32..63
+            const bool act = upper ? own : partner;
+            if (act)
+                unsafeAtomicAdd(&acc2[2ll * (upper ? pix : ppix) + (upper ? 0 : 1)],
+                                upper ? w : (double)pc);
+        }
     }
-    NXC_DEV void add(int p, double wt, double *image, unsigned long long *counts, int dbg)
+    // one sample (has: this lane has one, in pixel p with weight wt)
+    NXC_DEV void put(bool has, int p, double wt, double *__restrict__ acc2)
     {
-        if (p != pix) {
-            flush(image, counts, dbg);
-            pix = p;
+        flush_pairs(has && pix >= 0 && p != pix, acc2);
+        if (has) {
+            if (p != pix) { pix = p; w = 0.0; c = 0; }
+            w += wt;
+            c += 1;
         }
-        w += wt;
-        c += 1;
+    }
+    NXC_DEV void drain(double *__restrict__ acc2)
+    {
+        flush_pairs(pix >= 0, acc2);
+        pix = -1; w = 0.0; c = 0;
     }
 };
 
-// Weighs one sample and hands it to the lane's pixel accumulator.  Returns 1 if the sample fell
-// inside the image.  Samples outside the image skip the weight (only its finiteness assert is
-// kept: the weight is finite iff frac and the radial velocity are).
-NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y, double z,
-                         double vy, double frac, double *image, unsigned long long *counts,
-                         unsigned long long &nonfinite, PixelAcc &acc)
+// Weighs one sample: returns its pixel index (ix*nz + iz) and weight, or -1 if it falls outside
+// the image.  Samples outside the image skip the weight (only its finiteness assert is kept: the
+// weight is finite iff frac and the radial velocity are).
+NXC_DEV int image_weigh(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                        double vy, double frac, double &w_out, unsigned long long &nonfinite)
 {
     if (R.downcast) {
         x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
@@ -664,7 +690,7 @@ NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y
     const int iz = bin_index(zo, R.zedges, R.nz, R.z_lo, R.z_hi, R.z_inv_step);
     if (ix < 0 || iz < 0) {
         if (!(__builtin_fabs(frac) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;
-        return 0;
+        return -1;
     }
     const double s_obs = xo * xo + zo * zo;                        // ModelImage.py:252-254
     const bool inview = (s_obs > 0x1.0000000000001p+0) || (yo < 0.0);
@@ -682,6 +708,6 @@ NXC_DEV int image_sample(const ImageK &G, const ImageRegs &R, double x, double y
     }
     w = nxc_div_const(w, G.apix_cm2, lds_header().Wt.rs_apix);     // ModelImage.py:262
     if (!(__builtin_fabs(w) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;   // :170
-    acc.add(ix * R.nz + iz, w, image, counts, R.dbg);
-    return 1;
+    w_out = w;
+    return ix * R.nz + iz;
 }

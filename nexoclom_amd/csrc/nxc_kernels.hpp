@@ -138,8 +138,8 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
              int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t first_id,
              int64_t n_iter, double edge2, double *__restrict__ traj, int64_t nrec,
              double *__restrict__ final_out, long long *__restrict__ steps_out,
-             double *__restrict__ image, unsigned long long *__restrict__ counts,
-             DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr)
+             double *__restrict__ acc2, DevCounters *__restrict__ ctr,
+             const double *__restrict__ moon_pos = nullptr)
 {
     stage_tables(blob, stage_bytes);
     const LutView T = lut_view(F.tab);
@@ -148,21 +148,33 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
     PixelAcc acc;
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        double s[8], d[8];
+    const bool valid = i < n;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d[8];
+    if (valid) {
 #pragma unroll
         for (int c = 0; c < 8; c++) s[c] = soa0[c * n + i];
 #pragma unroll
         for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec) * n + i] = s[c];
-        bool alive = s[7] > 0.0;
+    }
+    bool alive = valid && s[7] > 0.0;
+    long long k = 0;
+    int nbounce = 0;
+    // The loop is wave-uniform (it runs while any lane still has steps to take) because the image
+    // accumulator is wave-cooperative; each lane works under its own predicate.
+    {
+        int p = -1;
+        double wt = 0.0;
         if (IMAGE && alive) {
             my_samples++;
-            my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                      my_nonfinite, acc);
+            p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
+            my_binned += p >= 0;
         }
-        long long k = 0;
-        int nbounce = 0;
-        while (alive && k < n_iter) {
+        if (IMAGE) acc.put(p >= 0, p, wt, acc2);
+    }
+    while (__ballot(alive && k < n_iter) != 0) {
+        int p = -1;
+        double wt = 0.0;
+        if (alive && k < n_iter) {
             if (NBODY) {
                 const BodyK *Bd = &lds_header().Bd;
                 const double *mp = moon_pos + k * (12 * Bd->n_moons);
@@ -180,17 +192,20 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
             alive = s[7] > 0.0;
             if (IMAGE && alive) {
                 my_samples++;
-                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image, counts,
-                                          my_nonfinite, acc);
+                p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
+                my_binned += p >= 0;
             }
         }
+        if (IMAGE) acc.put(p >= 0, p, wt, acc2);
+    }
+    if (valid) {
         if (final_out) {
 #pragma unroll
             for (int c = 0; c < 8; c++) final_out[c * n + i] = s[c];
         }
         if (steps_out) steps_out[i] = k;
     }
-    if (IMAGE) acc.flush(image, counts, IR.dbg);
+    if (IMAGE) acc.drain(acc2);
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -334,9 +349,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
               const unsigned *__restrict__ order, int64_t first_id, int64_t n_iter,
               double edge2, double *__restrict__ final_out,
-              long long *__restrict__ steps_out, double *__restrict__ image,
-              unsigned long long *__restrict__ counts, DevCounters *__restrict__ ctr,
-              const double *__restrict__ moon_pos = nullptr)
+              long long *__restrict__ steps_out, double *__restrict__ acc2,
+              DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr)
 {
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n);
     const LutView T = lut_view(F.tab);
@@ -358,6 +372,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         const long long got = q.refill(!has, stage_off, s);
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
         if (__ballot(has) == 0) break;
+        int p = -1;
+        double wt = 0.0;
         if (has) {
             if (!fresh) {
                 if (NBODY) {
@@ -375,8 +391,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             const bool live = s[7] > 0.0;
             if (IMAGE && live) {
                 my_samples++;
-                my_binned += image_sample(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], image,
-                                          counts, my_nonfinite, acc);
+                p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
+                my_binned += p >= 0;
             }
             if (!live || k >= n_iter) {
                 const LoopK &L = lds_header().L;
@@ -389,8 +405,9 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 has = false;
             }
         }
+        if (IMAGE) acc.put(p >= 0, p, wt, acc2);      // wave-cooperative: outside `if (has)`
     }
-    if (IMAGE) acc.flush(image, counts, IR.dbg);
+    if (IMAGE) acc.drain(acc2);
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -493,20 +510,27 @@ __global__ void __launch_bounds__(NXC_BLOCK)
 k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
         const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
         const double *__restrict__ vy, const double *__restrict__ frac,
-        double *__restrict__ image, unsigned long long *__restrict__ counts,
-        DevCounters *__restrict__ ctr)
+        double *__restrict__ acc2, DevCounters *__restrict__ ctr)
 {
     stage_tables(blob, stage_bytes);
     const ImageRegs IR = image_regs(lds_header().G);
     PixelAcc acc;
     unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        my_samples++;
-        my_binned += image_sample(lds_header().G, IR, x[i], y[i], z[i], vy[i], frac[i], image, counts,
-                                  my_nonfinite, acc);
+    // wave-uniform trip count (the accumulator is wave-cooperative); the last trip is ragged
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < p;
+         base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        int pidx = -1;
+        double wt = 0.0;
+        if (i < p) {
+            my_samples++;
+            pidx = image_weigh(lds_header().G, IR, x[i], y[i], z[i], vy[i], frac[i], wt,
+                               my_nonfinite);
+            my_binned += pidx >= 0;
+        }
+        acc.put(pidx >= 0, pidx, wt, acc2);
     }
-    acc.flush(image, counts, IR.dbg);
+    acc.drain(acc2);
     flush_counter(&ctr->samples, my_samples);
     flush_counter(&ctr->samples_binned, my_binned);
     flush_counter(&ctr->nonfinite, my_nonfinite);

@@ -25,6 +25,18 @@ __global__ void k(void *buf, uint32_t npix_mask, int iters, float hot)
         else if (MODE == 5) { unsafeAtomicAdd(&d[2 * pix], 1.0); atomicAdd(&u[2 * pix + 1], 1ull); }   // interleaved pair
         else if (MODE == 6) __hip_atomic_fetch_add(&u[pix], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else if (MODE == 7) d[pix] += 1.0;   // non-atomic RMW (for reference; racy)
+        else if (MODE == 8) {   // lane pairs (2k, 2k+1) add to the two halves of one 16-B pixel record
+            uint32_t ppix = __shfl(pix, (threadIdx.x & 63) & ~1u, 64);
+            unsafeAtomicAdd(&d[2 * ppix + (threadIdx.x & 1)], 1.0);
+        }
+        else if (MODE == 9) {   // lanes l and l+32 add to the two halves of one 16-B pixel record
+            uint32_t ppix = __shfl(pix, (threadIdx.x & 31), 64);
+            unsafeAtomicAdd(&d[2 * ppix + ((threadIdx.x >> 5) & 1)], 1.0);
+        }
+        else if (MODE == 10) {  // groups of 4 lanes add to 4 consecutive doubles (one 32-B half line)
+            uint32_t ppix = __shfl(pix, (threadIdx.x & 63) & ~3u, 64);
+            unsafeAtomicAdd(&d[(2 * ppix & ~3u) + (threadIdx.x & 3)], 1.0);
+        }
     }
 }
 
@@ -55,6 +67,9 @@ int main()
         run<5>("f64+u64 interleaved pair", buf, mask, hot);
         run<6>("u64 wavefront scope", buf, mask, hot);
         run<7>("f64 plain RMW (racy)", buf, mask, hot);
+        run<8>("f64 pair, adjacent lanes", buf, mask, hot);
+        run<9>("f64 pair, lanes l / l+32", buf, mask, hot);
+        run<10>("f64 quad, adjacent lanes", buf, mask, hot);
     }
     return 0;
 }
