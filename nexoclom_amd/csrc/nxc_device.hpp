@@ -629,6 +629,13 @@ NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 // only when the pixel changes (a 30 s step moves a packet by about one 512^2 pixel).  The packet
 // counts stay exact; the weighted sum only changes its (already arbitrary) summation order.
 // put() and drain() are wave-cooperative: all 64 lanes must call them from uniform control flow.
+// value held by lane l ^ 32 (v_permlane32_swap: one VALU instruction, no LDS crossbar trip)
+NXC_DEV int half_swap(int v, bool upper)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return upper ? (int)r[0] : (int)r[1];
+}
+
 struct PixelAcc {
     int pix = -1;                 // nx*nz < 2^31 (checked by nxc_set_image)
     double w = 0.0;
@@ -637,9 +644,9 @@ struct PixelAcc {
     NXC_DEV void flush_pairs(bool need, double *__restrict__ acc2)
     {
         if (__ballot(need) == 0) return;
-        const int ppix = __shfl_xor(need ? pix : -1, 32, 64);     // partner lane's pending pixel
-        const unsigned pc = (unsigned)__shfl_xor((int)c, 32, 64);
         const bool upper = (threadIdx.x & 32) != 0;
+        const int ppix = half_swap(need ? pix : -1, upper);       // partner lane's pending pixel
+        const unsigned pc = (unsigned)half_swap((int)c, upper);
         const bool own = need && w != 0.0;                         // a zero sum adds nothing
         const bool partner = ppix >= 0;
         {   // samples of lanes 0..31
