@@ -357,12 +357,15 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
     PixelAcc acc;
-    unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
+    // per-lane tallies fit 32 bits (a lane makes < 2^31 trips); widened when flushed
+    unsigned my_steps = 0, my_samples = 0, my_binned = 0;
+    unsigned long long my_nonfinite = 0;
     WaveQueue q;
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
     bool has = false, fresh = false;
-    long long id = -1, k = 0;
-    int nbounce = 0;
+    long long id = -1;
+    int k = 0, nbounce = 0;
+    const int n_it = n_iter > 0x7fffffffll ? 0x7fffffff : (int)n_iter;
     double s[8], d[8];
     // Per lane: a packet taken from the queue spends its first trip through the loop only being
     // binned (record 0), every later trip advancing one step and being binned again, so that the
@@ -378,7 +381,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             if (!fresh) {
                 if (NBODY) {
                     const BodyK *Bd = &lds_header().Bd;
-                    const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                    const double *mp = moon_pos + (long long)k * (12 * Bd->n_moons);
                     rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
                     apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
                 } else {
@@ -394,7 +397,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
                 my_binned += p >= 0;
             }
-            if (!live || k >= n_iter) {
+            if (!live || k >= n_it) {
                 const LoopK &L = lds_header().L;
                 if (double *fo = L.final_out) {
                     const long long np = L.n;

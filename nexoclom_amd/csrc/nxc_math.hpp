@@ -126,11 +126,15 @@ NXC_DEV double nxc_exp(double x)
     constexpr double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                      P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
                      P5 = 4.13813679705723846039e-08;
-    if (x != x) return x;
-    if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
-    if (x < -7.45133219101941108420e+02) return 0.0;
     const double ax = __builtin_fabs(x);
-    if (ax < 3.725290298461914e-09) return 1.0 + x;
+    // one test sends NaN, overflow, underflow and the tiny arguments to the rare path
+    if (__builtin_expect(!(ax >= 3.725290298461914e-09 && ax <= 7.09782712893383973096e+02), 0)) {
+        if (x != x) return x;
+        if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
+        if (x < -7.45133219101941108420e+02) return 0.0;
+        if (ax < 3.725290298461914e-09) return 1.0 + x;
+        // -745.13 <= x < -709.78: falls through to the general path (denormal results)
+    }
     const int kq = (int)(INV_LN2 * x + (x < 0 ? -0.5 : 0.5));
     const int k1 = x < 0 ? -1 : 1;
     const int k = ax > 0.34657359027997264 ? (ax < 1.0397207708399179 ? k1 : kq) : 0;
@@ -154,12 +158,15 @@ NXC_DEV double nxc_log(double x)
                      L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
                      L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
                      L7 = 1.479819860511658591e-01;
-    if (x != x) return x;
-    if (x == 0.0) return -__builtin_huge_val();
-    if (x < 0.0) return __builtin_nan("");
-    if (x == __builtin_huge_val()) return x;
     int k = 0;
-    if (x < 2.2250738585072014e-308) { x *= 18014398509481984.0; k = -54; }
+    // one test sends NaN, zero, negatives, infinity and subnormals to the rare path
+    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) {
+        if (x != x) return x;
+        if (x == 0.0) return -__builtin_huge_val();
+        if (x < 0.0) return __builtin_nan("");
+        if (x == __builtin_huge_val()) return x;
+        x *= 18014398509481984.0; k = -54;          // subnormal
+    }
     unsigned long long u = (unsigned long long)__double_as_longlong(x);
     int hx = (int)(u >> 32);
     k += (hx >> 20) - 1023;
