@@ -149,8 +149,11 @@ int nxc_set_first_index(nxc_handle *h, int64_t first_index);  /* RNG counter of 
  * Moon m moves on a circle of radius a[m] in the planet's equatorial (x, y) plane; its orbital
  * phase is phi[m] at t_remaining = 0 (geometry.phi: 0 = superior conjunction (+y), pi/2 = over
  * the dawn terminator (-x), docs/nexoclom/inputfiles.rst:72-77) and phi[m] - omega[m] t at
- * t_remaining = t:  r_m = a (-sin, cos, 0).  Applies to nxc_integrate_const* only (every packet
- * starts at t_remaining = t0); nxc_state / nxc_rk5_step / nxc_integrate_var and surface
+ * t_remaining = t:  r_m = a (-sin, cos, 0).  At stage n (Dormand-Prince node c_n) of step k the
+ * phase is evaluated as theta_k + delta_n, theta_k = phi - omega (t0 - k h), delta_n = omega c_n h,
+ * with sin/cos of the sum formed from the two sincos() pairs by the angle-addition formulas (that
+ * is the definition; the oracles follow it to the bit).  Applies to nxc_integrate_const* only
+ * (every packet starts at t_remaining = t0); nxc_state / nxc_rk5_step / nxc_integrate_var and surface
  * re-emission refuse to run while bodies are set.  NULL or n_moons == 0 && !chx_on clears. */
 #define NXC_MAX_MOONS 4
 typedef struct nxc_bodies_desc {

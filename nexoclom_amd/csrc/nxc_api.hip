@@ -225,7 +225,7 @@ struct nxc_handle {
 
     bool have_bodies = false;
     nxc_bodies_desc bodies{};
-    double *d_moonpos = nullptr;     // [n_iter][6 stages][n_moons][x, y]
+    double *d_moonpos = nullptr;     // [n_iter][n_moons][cos, sin] of the per-step base phase
     size_t moonpos_cap = 0;
 
     ncclComm_t comm = nullptr;
@@ -356,32 +356,39 @@ size_t persist_lds(size_t table_bytes)
     return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
 }
 
-// Moon positions at the six stage times of every step: t = t0 - (k + c_n) h, phase phi - omega t,
-// r_m = a (-sin, cos).  Host libm sincos(); the oracle builds the same table the same way.
+// Per-step base phases of the moons, (cos, sin)(phi - omega (t0 - k h)), and the per-stage rotations
+// (cos, sin)(omega c_n h) in the header.  Host libm sincos(); the oracle builds the same numbers
+// the same way.
 int upload_moon_table(nxc_handle *h, double step, int64_t n_iter)
 {
     static const double cn[6] = {0, 0.2, 0.3, 0.8, 8. / 9., 1.};
     const nxc_bodies_desc &b = h->bodies;
     const int nm = b.n_moons;
-    const size_t count = (size_t)(n_iter > 0 ? n_iter : 1) * 12 * (size_t)(nm > 0 ? nm : 1);
-    std::vector<double> pos(count, 0.0);
-    for (int64_t k = 0; k < n_iter; k++)
-        for (int n = 0; n < 6; n++) {
-            const double t = b.t0 - ((double)k + cn[n]) * step;
-            for (int m = 0; m < nm; m++) {
-                const double ang = b.phi[m] - b.omega[m] * t;
-                double *p = &pos[(((size_t)k * 6 + n) * nm + m) * 2];
-                double sn, cs;
-                ::sincos(ang, &sn, &cs);     // the libm pair routine, as the oracle calls it
-                p[0] = -(b.a[m] * sn);
-                p[1] = b.a[m] * cs;
-            }
+    BodyK &K = h->header.Bd;
+    for (int n = 0; n < 6; n++)
+        for (int m = 0; m < nm; m++) {
+            double sn, cs;
+            ::sincos(b.omega[m] * (cn[n] * step), &sn, &cs);
+            K.cd[n][m] = cs; K.sd[n][m] = sn;
         }
+    HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, Bd), &h->header.Bd, sizeof(BodyK),
+                          hipMemcpyHostToDevice, h->stream));
+    const size_t count = (size_t)(n_iter > 0 ? n_iter : 1) * 2 * (size_t)(nm > 0 ? nm : 1);
+    std::vector<double> base(count, 0.0);
+    for (int64_t k = 0; k < n_iter; k++) {
+        const double t = b.t0 - (double)k * step;
+        for (int m = 0; m < nm; m++) {
+            double sn, cs;
+            ::sincos(b.phi[m] - b.omega[m] * t, &sn, &cs);
+            base[((size_t)k * nm + m) * 2] = cs;
+            base[((size_t)k * nm + m) * 2 + 1] = sn;
+        }
+    }
     int rc = ensure(reinterpret_cast<void **>(&h->d_moonpos), &h->moonpos_cap,
                     count * sizeof(double));
     if (rc) return rc;
     // pageable source: the copy is staged before the call returns
-    HIPCHK(hipMemcpyAsync(h->d_moonpos, pos.data(), count * sizeof(double), hipMemcpyHostToDevice,
+    HIPCHK(hipMemcpyAsync(h->d_moonpos, base.data(), count * sizeof(double), hipMemcpyHostToDevice,
                           h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
@@ -418,6 +425,9 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
         if (h->have_bounce)
             return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
         if ((rc = upload_moon_table(h, step, n_iter))) return rc;
+        if (h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO)
+            return image ? launch_fused<true, false, true, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
+                         : launch_fused<false, false, true, true>(h, tables, lds, n_iter, edge2, d_final, d_steps);
         return image ? launch_fused<true, false, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps)
                      : launch_fused<false, false, false, true>(h, tables, lds, n_iter, edge2, d_final, d_steps);
     }
@@ -700,6 +710,7 @@ int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d)
         for (int m = 0; m < d->n_moons; m++) {
             K.gm[m] = d->gm[m];
             K.rad2[m] = d->radius[m] * d->radius[m];
+            K.a[m] = d->a[m];
         }
         K.chx_on = d->chx_on ? 1 : 0;
         if (K.chx_on) {

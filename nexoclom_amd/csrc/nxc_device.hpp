@@ -170,23 +170,41 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
 // particle_tracking/state.py:5-10,56-70, but refuses such runs, Output.py:153-155).
 //   gravity   a += GM_m (r - r_m) / |r - r_m|^3      for every included moon
 //   loss      rate += k0 exp(-((rho - rho0)/w)^2 - (z/H)^2) [* |v - Omega z^ x r| / (Omega rho0)]
-// Moons move on prescribed circles in the planet's equatorial (x, y) plane.  Their positions
-// at the six stage times of every step come from a host-built table pos[step][stage][moon][2].
+// Moons move on prescribed circles in the planet's equatorial (x, y) plane.  The orbital phase at
+// stage n of step k is theta_k + delta_n with theta_k = phi - omega (t0 - k h) and
+// delta_n = omega c_n h; the host tabulates (cos, sin) theta_k per step (base[step][moon][2], two
+// doubles per moon per step from L2) and (cos, sin) delta_n per stage (here), and the position is
+// formed with the angle-addition formulas -- the oracles do exactly the same:
+//   r_m = a (-(S cd + C sd), C cd - S sd, 0)
 constexpr int NXC_DEV_MAX_MOONS = 4;   // == NXC_MAX_MOONS of the C ABI
 struct BodyK {
     int n_moons, chx_on, chx_vel, pad_;
-    double gm[NXC_DEV_MAX_MOONS], rad2[NXC_DEV_MAX_MOONS];
+    double gm[NXC_DEV_MAX_MOONS], rad2[NXC_DEV_MAX_MOONS], a[NXC_DEV_MAX_MOONS];
+    double cd[6][NXC_DEV_MAX_MOONS], sd[6][NXC_DEV_MAX_MOONS];
     double chx_k0, chx_rho0, chx_inv_w, chx_inv_h, chx_omega, chx_inv_v0;
 };
 
-// Moon gravity and torus loss added to state_eval's result.  mp: this stage's moon positions
-// (x, y per moon).  Generic-range sqrt / division: moons are approached closely.
-NXC_DEV void bodies_eval(const BodyK &Bd, const double *__restrict__ mp, double x, double y,
-                         double z, double vx, double vy, double vz, double &ax, double &ay,
-                         double &az, double &ion)
+NXC_DEV void moon_position(const BodyK &Bd, const double *__restrict__ base, int m, int stage,
+                           double &mx, double &my)
+{
+    const double C = base[2 * m], S = base[2 * m + 1];
+    const double cd = Bd.cd[stage][m], sd = Bd.sd[stage][m];
+    const double sn = S * cd + C * sd;
+    const double cs = C * cd - S * sd;
+    mx = -(Bd.a[m] * sn);
+    my = Bd.a[m] * cs;
+}
+
+// Moon gravity and torus loss added to state_eval's result.  base: (cos, sin) theta_k of this
+// step per moon.  Generic-range sqrt / division: moons are approached closely.
+NXC_DEV void bodies_eval(const BodyK &Bd, const double *__restrict__ base, int stage, double x,
+                         double y, double z, double vx, double vy, double vz, double &ax,
+                         double &ay, double &az, double &ion)
 {
     for (int m = 0; m < Bd.n_moons; m++) {
-        const double dx = x - mp[2 * m], dy = y - mp[2 * m + 1];
+        double mx, my;
+        moon_position(Bd, base, m, stage, mx, my);
+        const double dx = x - mx, dy = y - my;
         const double r3 = nxc_cube(nxc_sqrt((dx * dx + dy * dy) + z * z));
         const double g = Bd.gm[m];
         double qx, qy, qz;
@@ -251,8 +269,7 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
         kv[n][0] = vx; kv[n][1] = vy; kv[n][2] = vz;
         state_eval<FULL>(F, T, px, py, pz, vy, ka[n][0], ka[n][1], ka[n][2], kl[n]);
         if (NBODY)
-            bodies_eval(*Bd, mp + n * Bd->n_moons * 2, px, py, pz, vx, vy, vz, ka[n][0], ka[n][1],
-                        ka[n][2], kl[n]);
+            bodies_eval(*Bd, mp, n, px, py, pz, vx, vy, vz, ka[n][0], ka[n][1], ka[n][2], kl[n]);
         // The reference starts each sum from 0.0 (0 + t0): dropped, it can only change the sign
         // of an exactly-zero sum.
         double nx, ny, nz, nvx, nvy, nvz, nlf;
@@ -508,7 +525,7 @@ NXC_DEV void bounce_packet(const BounceK &B, double (&s)[8], double r2, unsigned
 // the escape test still uses the pre-impact radius, as the reference's tempR does.
 template <bool BOUNCE, bool NBODY = false>
 NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int &nbounce,
-                        const BodyK *Bd = nullptr, const double *__restrict__ mp_end = nullptr)
+                        const BodyK *Bd = nullptr, const double *__restrict__ base = nullptr)
 {
     const double r2 = (s[1] * s[1] + s[2] * s[2]) + s[3] * s[3];
     if (r2 < 1.0) {
@@ -518,7 +535,9 @@ NXC_DEV void apply_fate(double (&s)[8], double edge2, unsigned long long id, int
     if (r2 > edge2) s[7] = 0.0;
     if (NBODY) {                    // absorbed by a moon (positions at the end of the step)
         for (int m = 0; m < Bd->n_moons; m++) {
-            const double dx = s[1] - mp_end[2 * m], dy = s[2] - mp_end[2 * m + 1];
+            double mx, my;
+            moon_position(*Bd, base, m, 5, mx, my);
+            const double dx = s[1] - mx, dy = s[2] - my;
             if ((dx * dx + dy * dy) + s[3] * s[3] < Bd->rad2[m]) s[7] = 0.0;
         }
     }

@@ -177,9 +177,9 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         if (alive && k < n_iter) {
             if (NBODY) {
                 const BodyK *Bd = &lds_header().Bd;
-                const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                const double *mp = moon_pos + k * (2 * Bd->n_moons);
                 rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
-                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp);
             } else {
                 rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
                 apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
@@ -250,9 +250,9 @@ k_const_rows(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_byt
             const double before = s[7];
             if (NBODY) {
                 const BodyK *Bd = &lds_header().Bd;
-                const double *mp = moon_pos + k * (12 * Bd->n_moons);
+                const double *mp = moon_pos + k * (2 * Bd->n_moons);
                 rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
-                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp);
             } else {
                 rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
                 apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
@@ -381,9 +381,9 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             if (!fresh) {
                 if (NBODY) {
                     const BodyK *Bd = &lds_header().Bd;
-                    const double *mp = moon_pos + (long long)k * (12 * Bd->n_moons);
-                    rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
-                    apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp + 10 * Bd->n_moons);
+                    const double *mp = moon_pos + (long long)k * (2 * Bd->n_moons);
+                    rk5_step<false, true, FULL, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
+                    apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp);
                 } else {
                     rk5_step<false, true, FULL>(F, T, s, 0.0, lds_header().W, d);
                     apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);

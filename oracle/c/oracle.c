@@ -119,14 +119,21 @@ typedef struct {
 
 static const double CSTAGE[6] = {0, 0.2, 0.3, 0.8, 8./9., 1.};
 
+/* Phase at stage n of step k = theta_k + delta_n, theta_k = phi - omega (t0 - k h),
+ * delta_n = omega c_n h; both sincos() pairs are formed separately and combined with the
+ * angle-addition formulas (the definition of include/nexoclom_hip.h: the device gets theta_k from a
+ * per-step table and delta_n from six constants).  sincos() explicitly: compilers merge sin + cos
+ * into it at some optimisation levels, and its results are not always those of the separate
+ * calls. */
 static inline void moon_xy(const ora_bodies *b, int m, int64_t k, int stage, double h,
                            double *mx, double *my)
 {
-    double t = b->t0 - ((double)k + CSTAGE[stage]) * h;
-    double ang = b->phi[m] - b->omega[m] * t, sn, cs;
-    sincos(ang, &sn, &cs);      /* explicitly the libm pair routine: compilers merge sin + cos
-                                   into it at some optimisation levels, and its results are not
-                                   always those of the separate calls */
+    double t = b->t0 - (double)k * h;
+    double S, C, sd, cd;
+    sincos(b->phi[m] - b->omega[m] * t, &S, &C);
+    sincos(b->omega[m] * (CSTAGE[stage] * h), &sd, &cd);
+    double sn = S * cd + C * sd;
+    double cs = C * cd - S * sd;
     *mx = -(b->a[m] * sn);
     *my = b->a[m] * cs;
 }

@@ -625,11 +625,17 @@ _STAGE_C = (0., 0.2, 0.3, 0.8, 8./9., 1.)
 
 def moon_xy(b: Bodies, m, k, stage, h):
     """Position of moon m at stage `stage` of step k: circle in the (x, y) plane, phase
-    phi - omega*t at t_remaining = t; phi = pi/2 is over the dawn terminator (-x)."""
+    theta_k + delta_n with theta_k = phi - omega*(t0 - k*h), delta_n = omega*c_n*h, combined by
+    the angle-addition formulas (as the device does from its per-step table); phi = pi/2 is over
+    the dawn terminator (-x)."""
     import math
-    t = b.t0 - (float(k) + _STAGE_C[stage])*h
-    ang = b.phi[m] - b.omega[m]*t
-    return -(b.a[m]*math.sin(ang)), b.a[m]*math.cos(ang)
+    t = b.t0 - float(k)*h
+    th = b.phi[m] - b.omega[m]*t
+    dl = b.omega[m]*(_STAGE_C[stage]*h)
+    S, C, sd, cd = math.sin(th), math.cos(th), math.sin(dl), math.cos(dl)
+    sn = S*cd + C*sd
+    cs = C*cd - S*sd
+    return -(b.a[m]*sn), b.a[m]*cs
 
 
 def state_bodies(x, f: Forces, b: Bodies, k, stage, h):
