@@ -377,7 +377,9 @@ class Output:
         """Apply the reference's on-disk transformations (compress filter, 32-bit down-cast,
         Output.py:522-543), register in the inputs' catalogue, optionally write an .npz."""
         if self.compress and len(self.X) > 0 and 'frac' in self.X:
-            self.X = self.X[self.X.frac > 0]
+            keep = self.X.frac.values > 0
+            if not keep.all():          # the compact-rows path already delivers only these rows
+                self.X = self.X[keep]
         for frame in (self.X0, self.X):
             for column in frame:
                 if frame[column].dtype == np.int64:
