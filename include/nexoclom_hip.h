@@ -10,12 +10,18 @@
  *   nxc_rk5_step           rk5(output, X0, h)                     particle_tracking/rk5.py:21-54
  *   nxc_integrate_const    Output.constant_step_size_driver()     particle_tracking/Output.py:368-455
  *                          (+ optionally fused ModelImage.create_image of every stored step)
+ *   nxc_integrate_const_rows / nxc_rows_fetch
+ *                          the same driver followed by save()'s   particle_tracking/Output.py:523-524
+ *                          frac > 0 row filter
  *   nxc_integrate_var      Output.variable_step_size_driver()     particle_tracking/Output.py:221-366
  *   nxc_image_accumulate   ModelImage.create_image()              data_simulation/ModelImage.py:229-274
  *                          + ModelResult.packet_weighting()       data_simulation/ModelResult.py:140-170
  *                          + Histogram2d()                        math/histogram.py:28-39
  *   nxc_image_allreduce    the per-output-file image sum          data_simulation/ModelImage.py:96-98
  *   nxc_los_accumulate     compute_iteration() inner work          data_simulation/compute_iteration.py:138-217
+ *   nxc_set_bounce         bouncepackets() inside the drivers     particle_tracking/bouncepackets.py:5-100
+ *   nxc_packets_sample     surface/speed/angular_distribution()   initial_state/source_distribution.py:37-283
+ *   nxc_set_bodies         (extension) moons + plasma-torus loss  equations: particle_tracking/state.py:5-10
  *
  * Conventions
  *   - Every function returns 0 on success or a negative nxc_status; nothing is thrown across the
