@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libnexoclom_hip.so')
+# NEXOCLOM_HIP_LIB: load another build of the same library (installation elsewhere, experiments)
+LIB_PATH = os.environ.get('NEXOCLOM_HIP_LIB') or os.path.join(_HERE, 'lib', 'libnexoclom_hip.so')
 _dp = C.POINTER(C.c_double)
 NXC_MAX_LINES = 4
 NXC_RUN_IMAGE = 1
