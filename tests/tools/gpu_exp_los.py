@@ -1,7 +1,7 @@
 """Timing of the LOS cone kernel and the stand-alone image kernel on stored samples."""
 import os, sys, time, io, contextlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from nexoclom_amd import Input, Output, ModelImage, LOSResult, SpacecraftData, hip_api
 from nexoclom_amd.LOSResult import los_geometry, arccos_threshold
