@@ -57,3 +57,24 @@ def test_package_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
                 assert 'oracle_math.h' not in src and 'liboracle' not in src, fn
+    # tools/ are measurement helpers of the product: no oracle there either, directly or through
+    # the test helpers (scripts that need them live in tests/tools/)
+    for fn in os.listdir(os.path.join(ROOT, 'tools')):
+        if fn.endswith('.py'):
+            src = open(os.path.join(ROOT, 'tools', fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+(oracle|tests)\b', src, flags=re.M), fn
+    # bench.py touches the oracle only inside its cpu_baseline leg; __graft_entry__ only in smoke()
+    import ast
+    for fn, allowed in (('bench.py', {'cpu_baseline'}), ('__graft_entry__.py', {'smoke'})):
+        tree = ast.parse(open(os.path.join(ROOT, fn)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef):
+                uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                           ('oracle' in (getattr(n, 'module', '') or '') or
+                            any('oracle' in a.name for a in n.names))
+                           for n in ast.walk(node))
+                assert not uses or node.name in allowed, (fn, node.name)
+        for node in tree.body:          # and never at module level
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                mod = getattr(node, 'module', '') or ''
+                assert 'oracle' not in mod and all('oracle' not in a.name for a in node.names), fn
