@@ -79,11 +79,23 @@ NXC_DEV LutView lut_view(const LutDesc &d)
 // A NaN abscissa is clamped like any other value (np.interp would return NaN): callers that must
 // notice it test their argument themselves; in the integrator a NaN velocity has already made
 // the position NaN.
+// SCALAR_BOUNDS: the view's x0 / xlast sit in scalar registers (descriptor passed as a kernel
+// argument), so they can be the instruction's scalar operand directly.
+template <bool SCALAR_BOUNDS = false>
 NXC_DEV double lut_interp(const LutView &t, double xin)
 {
     // Clamping to [x0, xlast] reproduces np.interp's end values exactly: at x0 record 0 gives
     // slope*0 + fp[0]; the last record has slope 0.
-    const double x = __builtin_fmin(__builtin_fmax(xin, t.x0), t.xlast);
+    // fmax/fmin as the bare instructions: through the builtins the compiler first canonicalises
+    // the (wave-uniform, never signalling) table bounds with an extra v_max_f64 each, every call
+    double x;
+    if (SCALAR_BOUNDS) {
+        asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(xin), "s"(t.x0));
+        asm("v_min_f64 %0, %1, %2" : "=v"(x) : "v"(x), "s"(t.xlast));
+    } else {
+        asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(xin), "v"(t.x0));
+        asm("v_min_f64 %0, %1, %2" : "=v"(x) : "v"(x), "v"(t.xlast));
+    }
     int c = (int)((x - t.x0) * t.inv_w);
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
@@ -154,7 +166,7 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
         const double vv = vy + F.vrplanet;
         // interp * out_of_shadow: the product with False is a zero whose sign cannot matter in
         // gy + ry
-        const double a = lut_interp(T, vv);
+        const double a = lut_interp<true>(T, vv);
         ry = lit ? a : 0.0;
     }
     ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
