@@ -115,9 +115,10 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
     int ncell = 64;
     while (ncell < cells_per_node * n && ncell < 16384) ncell <<= 1;
     const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 31) & ~size_t(31);
-    out.bytes.assign((size_t)n * 32 + cell_bytes, 0);
+    // n table rows + one sentinel row in each of the two 16-byte-stride arrays
+    out.bytes.assign((size_t)(n + 1) * 32 + cell_bytes, 0);
     double *rec = reinterpret_cast<double *>(out.bytes.data());
-    double *fs = rec + 2 * n;     // {fp, slope} pairs after the {xp, xp_next} pairs
+    double *fs = rec + 2 * (n + 1);     // {fp, slope} pairs after the {xp, xp_next} pairs
     for (int64_t j = 0; j < n; j++) {
         rec[2 * j + 0] = xp[j];
         fs[2 * j + 0] = fp[j];
@@ -131,7 +132,9 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
         if (!std::isfinite(fs[2 * j]) || !std::isfinite(fs[2 * j + 1]))
             return fail(NXC_ERR_ARG, std::string(what) + ": table values must be finite");
     }
-    unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * n);
+    rec[2 * n + 0] = HUGE_VAL; rec[2 * n + 1] = HUGE_VAL;      // sentinel: never selected
+    fs[2 * n + 0] = fp[n - 1]; fs[2 * n + 1] = 0.0;
+    unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * (n + 1));
     const double x0 = xp[0], xl = xp[n - 1];
     const double inv_w = (double)ncell / (xl - x0);
     for (int c = 0; c <= ncell; c++) {

@@ -69,8 +69,8 @@ NXC_DEV LutView lut_view(const LutDesc &d)
 {
     LutView v;
     v.rec = (int)d.offset_bytes;
-    v.fs = v.rec + 16 * d.n;
-    v.cell = v.rec + 32 * d.n;
+    v.fs = v.rec + 16 * (d.n + 1);        // each array carries one sentinel row after the table
+    v.cell = v.rec + 32 * (d.n + 1);
     v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast;
     v.f_first = d.f_first; v.f_last = d.f_last; v.inv_w = d.inv_w;
     return v;
@@ -99,9 +99,11 @@ NXC_DEV double lut_interp(const LutView &t, double xin)
     int c = (int)((x - t.x0) * t.inv_w);
     c = c < t.ncell ? c : t.ncell - 1;
     int j = lds_u16(t.cell + 2 * c);
-    const int j1 = j + 1 < t.n ? j + 1 : t.n - 1;
-    const double2 a0 = lds_f64x2(t.rec + 16 * j), a1 = lds_f64x2(t.rec + 16 * j1);
-    const double2 b0 = lds_f64x2(t.fs + 16 * j), b1 = lds_f64x2(t.fs + 16 * j1);
+    // rows j and j + 1 of both arrays: two address computations, the +16 is an immediate offset
+    // (row n is a sentinel {+inf, +inf} / {f_last, 0}, so j + 1 needs no clamp)
+    const int ra = t.rec + 16 * j, rb = ra + (t.fs - t.rec);
+    const double2 a0 = lds_f64x2(ra), a1 = lds_f64x2(ra + 16);
+    const double2 b0 = lds_f64x2(rb), b1 = lds_f64x2(rb + 16);
     const bool in0 = (x >= a0.x) && (x < a0.y);
     const bool in1 = (x >= a1.x) && (x < a1.y);
     LutRec r;
