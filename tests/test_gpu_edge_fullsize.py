@@ -120,6 +120,31 @@ def test_full_size_properties_1e6_packets(ctx):
     assert abs(sunward - tail)/(sunward + tail) > 0.2
 
 
+def test_full_size_parity_against_the_c_oracle(ctx, coracle):
+    """BASELINE configs[1] size against the C oracle itself (all host threads): final state of
+    every one of 1e6 packets, its step count and the 512 x 512 packet-count image bit for bit
+    (1.3e8 particle-steps, 6.5e7 binned samples), brightness to 1e-10.  With
+    NXC_PARITY_PACKETS=1e7 it is configs[2] at full size (1.28e9 particle-steps; passes, 44 s)."""
+    if coracle.max_threads() < 16:
+        pytest.skip('needs the GPU box\'s host cores to finish in seconds')
+    f, im = _setup(ctx, dims=(512, 512))
+    import os
+    n = int(float(os.environ.get('NXC_PARITY_PACKETS', 1_000_000)))   # 1e7 = configs[2], ~1 min
+    X0 = H.sample_x0(n, 4321, 50000.)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    ctx.upload_packets(X0)
+    g = ctx.integrate_const(30., n_iter, 25., image=True, want_final=True, want_steps=True)
+    image, counts = ctx.image_download()
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                              im['xedges'], im['zedges'])
+    c = coracle.integrate_const(f, X0, 30., n_iter, 25., img=desc, threads=coracle.max_threads())
+    assert ctx.counters()['particle_steps'] == c['work']
+    assert np.array_equal(g['steps'], c['steps'])
+    assert np.array_equal(g['final'], c['final'])
+    assert np.array_equal(counts, c['counts'])
+    np.testing.assert_allclose(image, c['image'], rtol=1e-10, atol=0)
+
+
 def test_gravity_only_energy_at_scale(ctx):
     """Energy conservation of the reference's test_gravity.py on 2e5 packets x 667 steps."""
     f = H.mercury_forces('Na', 3.14, True, False, 0.0)
