@@ -145,6 +145,26 @@ def test_full_size_parity_against_the_c_oracle(ctx, coracle):
     np.testing.assert_allclose(image, c['image'], rtol=1e-10, atol=0)
 
 
+def test_variable_driver_parity_at_scale(ctx, coracle):
+    """2e5 packets through the adaptive driver (random start times, as Output.py:138-139):
+    final states and stored step sizes bit-identical to the C oracle, same number of rk5
+    attempts."""
+    if coracle.max_threads() < 16:
+        pytest.skip('needs the GPU box\'s host cores to finish in seconds')
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    n = 200_000
+    X0 = H.sample_x0(n, 555, 50000.)
+    X0[:, 0] = np.random.default_rng(9).random(n)*50000.
+    ctx.upload_packets(X0)
+    final, hs = ctx.integrate_var(1e-4, 25.)
+    ctr = ctx.counters()
+    cf, chs, work, bad = coracle.integrate_var(f, X0, 1e-4, 25.)
+    assert bad == 0 and ctr['nonfinite'] == 0 and ctr['unfinished'] == 0
+    assert ctr['particle_steps'] == work
+    assert np.array_equal(final, cf) and np.array_equal(hs, chs)
+
+
 def test_gravity_only_energy_at_scale(ctx):
     """Energy conservation of the reference's test_gravity.py on 2e5 packets x 667 steps."""
     f = H.mercury_forces('Na', 3.14, True, False, 0.0)
