@@ -302,7 +302,8 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
 /* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
  * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other
  * ranks (any side channel); every rank then calls nxc_comm_init.  nxc_image_allreduce sums the
- * resident image (fp64) and counts (uint64) over all ranks in place. */
+ * resident image and packet counts over all ranks in place (one fp64 all-reduce: the device keeps
+ * {weight sum, count} interleaved, counts as integer-valued doubles, exact below 2^53). */
 #define NXC_UNIQUE_ID_BYTES 128
 int nxc_comm_unique_id(uint8_t id[NXC_UNIQUE_ID_BYTES]);
 int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank, int nranks);
