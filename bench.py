@@ -115,7 +115,8 @@ def main():
                   'center': '0,0'}
         img = ModelImage(inputs, params, context=ctx)      # parses params; no packets yet
     ctx.set_forces(**out.forces_kwargs())
-    img._set_image(ctx, out.aplanet, out.vrplanet, True)
+    aplanet, vrplanet = out.aplanet, out.vrplanet
+    img._set_image(ctx, aplanet, vrplanet, True)
     ctx.upload_soa(out.x0_soa())
     del out
 
@@ -207,6 +208,23 @@ def main():
                                  'resource is fp64 VALU issue (see DESIGN.md)'},
             'device': ctx.device_name(),
         }
+        if world == 1:
+            # the same pass with the other image quantity (configs[2] words it as a "column"
+            # image; the headline above uses the costlier radiance weighting), for reference
+            other = 'column' if args.quantity != 'column' else 'radiance'
+            with contextlib.redirect_stdout(io.StringIO()):
+                img2 = ModelImage(inputs, dict(params, quantity=other), context=ctx)
+            img2._set_image(ctx, aplanet, vrplanet, True)
+            ms2 = []
+            for it in range(3):
+                ctx.image_clear()
+                ctx.integrate_const_async(opt.step_size, n_iter, opt.outeredge, image=True)
+                ctx.synchronize()
+                if it:
+                    ms2.append(ctx.last_kernel_ms())
+            line['other_quantity'] = {'quantity': other, 'kernel_ms': float(np.mean(ms2)),
+                                      'value': ctr['particle_steps']/(float(np.mean(ms2))*1e-3),
+                                      'unit': 'particle*steps/s'}
         if world == 1 and not args.no_cpu_baseline:
             with contextlib.redirect_stdout(io.StringIO()):
                 line['cpu_baseline'] = cpu_baseline(args, inputs)
