@@ -112,6 +112,7 @@ const char *nxc_last_error_string(void);
 int nxc_create(int device, nxc_handle **out);
 int nxc_destroy(nxc_handle *h);
 int nxc_device_name(nxc_handle *h, char *buf, int buflen);
+int nxc_device_bus_id(nxc_handle *h, char *buf, int buflen);  /* PCI bus id, e.g. "0000:05:00.0" */
 int nxc_synchronize(nxc_handle *h);
 
 /* ---- set-up ---------------------------------------------------------------------------------- */
@@ -301,7 +302,8 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
 
 /* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
  * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other
- * ranks (any side channel); every rank then calls nxc_comm_init.  nxc_image_allreduce sums the
+ * ranks (any side channel); every rank then calls nxc_comm_init (NXC_ERR_ARG when RCCL refuses
+ * the layout, which is what happens when two ranks share one device).  nxc_image_allreduce sums the
  * resident image and packet counts over all ranks in place (one fp64 all-reduce: the device keeps
  * {weight sum, count} interleaved, counts as integer-valued doubles, exact below 2^53). */
 #define NXC_UNIQUE_ID_BYTES 128
@@ -310,6 +312,7 @@ int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank
 int nxc_comm_destroy(nxc_handle *h);
 int nxc_image_allreduce(nxc_handle *h);
 int nxc_allreduce_max_f64(nxc_handle *h, double *value);   /* control plane: max-over-ranks timer */
+int nxc_allreduce_sum_f64(nxc_handle *h, double *value);   /* control plane: whole-job work counters */
 int nxc_barrier(nxc_handle *h);
 
 /* ---- diagnostics used by the parity tests -------------------------------------------------------

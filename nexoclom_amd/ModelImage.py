@@ -123,7 +123,7 @@ class ModelResult:
 class ModelImage(ModelResult):
     def __init__(self, inputs, params, overwrite=False, distribute=None, *, npackets=None,
                  seed=None, packs_per_it=None, downcast=True, device=0, context=None,
-                 sampler='numpy', first_index=0, finalize=True):
+                 sampler='numpy', shard=None, finalize=True):
         super().__init__(inputs, params)
         self.type = 'image'
         self.origin = self.params.get('origin', inputs.geometry.planet)
@@ -161,7 +161,10 @@ class ModelImage(ModelResult):
         self.counters = {}
 
         if npackets is not None:
-            self._stream(int(npackets), seed, packs_per_it, downcast, sampler, first_index)
+            lo, hi = (0, int(npackets)) if shard is None else (int(shard[0]), int(shard[1]))
+            if not 0 <= lo <= hi <= int(npackets):
+                raise ValueError('shard must be an index range inside [0, npackets]')
+            self._stream(int(npackets), seed, packs_per_it, downcast, sampler, lo, hi)
         else:
             outputs = [o for o in inputs._catalogue]
             if not outputs:
@@ -228,32 +231,40 @@ class ModelImage(ModelResult):
         return (Histogram2dResult(image, self.xedges, self.zedges),
                 Histogram2dResult(counts.astype(float), self.xedges, self.zedges))
 
-    def _stream(self, npackets, seed, packs_per_it, downcast, sampler='numpy', first_index=0):
-        """Fused integrate + image over ``npackets`` packets, chunked like Input.run."""
+    def _stream(self, total, seed, packs_per_it, downcast, sampler='numpy', lo=0, hi=None):
+        """Fused integrate + image over the packets [lo, hi) of a run of ``total`` packets.
+
+        The run is cut into chunks like Input.run does (Input.py:243-246); the chunk grid depends
+        only on ``total`` and ``packs_per_it`` (distributed.chunk_plan), and chunk k of the host
+        sampler is drawn from the generator seeded ``seed + k``, so the packets with global index
+        in [lo, hi) are the same packets whether this process handles the whole run or one shard
+        of it.  The device sampler is counter-based on the global index."""
         from .Output import Output, n_output_steps
+        from .distributed import chunk_plan
         inputs = self.inputs
         opt = inputs.options
         if opt.step_size == 0:
             raise NotImplementedError('streaming images need constant-step inputs; the '
                                       'variable-step driver keeps one final row per packet')
+        hi = total if hi is None else hi
         ctx = self.context()
-        chunk = int(packs_per_it) if packs_per_it else min(npackets, 20_000_000)
+        chunk = int(packs_per_it) if packs_per_it else max(1, min(total, 20_000_000))
         nsteps, n_iter = n_output_steps(opt.endtime.value, float(opt.step_size))
-        done, k, first = 0, 0, True
+        first = True
         totals = {}
         src = bounce = bodies = None
-        while done < npackets:
-            n = min(chunk, npackets - done)
+        for k, c0, clen, a, b in chunk_plan(total, chunk, lo, hi):
+            n = b - a
             if sampler == 'device' and not first:
                 # same inputs, next slice of the counter space: no need to rebuild the tables
-                ctx.sample_packets(n, 0 if seed is None else seed, first_index + done, **src)
-            elif sampler == 'device':     # one counter space: chunk k continues at packet `done`
+                ctx.sample_packets(n, 0 if seed is None else seed, a, **src)
+            elif sampler == 'device':     # one counter space: packet i is draw block i
                 out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
-                             sampler='device', first_index=first_index + done,
-                             materialize_x0=False)
+                             sampler='device', first_index=a, materialize_x0=False)
                 src, bounce, bodies = out.source_desc(), out._bounce, out._bodies
             else:
-                out = Output(inputs, n, seed=None if seed is None else seed + k,
+                # the whole chunk is drawn (the generator is sequential), rows [a, b) are kept
+                out = Output(inputs, clen, seed=None if seed is None else seed + k,
                              integrate=False, save=False, context=ctx)
                 bounce, bodies = out._bounce, out._bodies
             if first:
@@ -261,19 +272,22 @@ class ModelImage(ModelResult):
                 self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
                 first = False
             if sampler != 'device':
-                out.upload(ctx)
+                soa = out.x0_soa()
+                ctx.upload_soa(soa if n == clen else np.ascontiguousarray(soa[:, a-c0:b-c0]))
             ctx.set_bounce(bounce)
             ctx.set_bodies(bodies)
-            ctx.set_first_index(first_index + done)
+            ctx.set_first_index(a)
             ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
             for key, v in ctx.counters().items():
                 totals[key] = totals.get(key, 0) + v
             self.totalsource += n * nsteps                                  # Output.py:434
             self.npackets += n
-            done += n
-            k += 1
         self.counters = totals
         assert totals.get('nonfinite', 0) == 0, 'Non-finite weights'
+        if first:       # an empty shard still owns a resident (zero) image for the reduce
+            out = Output(inputs, 0, seed=seed, integrate=False, save=False, context=ctx)
+            ctx.set_forces(**out.forces_kwargs())
+            self._set_image(ctx, out.aplanet, out.vrplanet, downcast)
         image, counts = ctx.image_download()
         self.image += image
         self.packet_image += counts.astype(float)

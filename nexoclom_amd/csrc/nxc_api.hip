@@ -543,6 +543,13 @@ int nxc_device_name(nxc_handle *h, char *buf, int buflen)
     return NXC_OK;
 }
 
+int nxc_device_bus_id(nxc_handle *h, char *buf, int buflen)
+{
+    if (!h || !buf || buflen < 16) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipDeviceGetPCIBusId(buf, buflen, h->device));
+    return NXC_OK;
+}
+
 int nxc_synchronize(nxc_handle *h)
 {
     if (!h) return fail(NXC_ERR_ARG, "null handle");
@@ -860,64 +867,24 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
     });
 }
 
-int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
-{
-    return guarded([&]() -> int {
-    if (!h || n < 0 || (n && !soa0)) return fail(NXC_ERR_ARG, "bad arguments");
-    HIPCHK(hipSetDevice(h->device));
-    const size_t bytes = (size_t)8 * n * sizeof(double);
-    int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
-    if (rc) return rc;
-    if (n) HIPCHK(hipMemcpyAsync(h->d_packets, soa0, bytes, hipMemcpyHostToDevice, h->stream));
-    // Queue order for the persistent kernels: counting sort of the packet indices by decreasing
-    // |v|^2 (4096 bins).  Fast packets live longest (escape to outeredge / bound orbits).
-    h->have_order = false;
-    if (n > 1 && n < (int64_t)0xffffffffll) {
-        std::vector<float> key((size_t)n);
-        float kmax = 0.f;
-        for (int64_t i = 0; i < n; i++) {
-            const double vx = soa0[4 * n + i], vy = soa0[5 * n + i], vz = soa0[6 * n + i];
-            const float k = (float)(vx * vx + vy * vy + vz * vz);
-            key[(size_t)i] = k;
-            if (k > kmax) kmax = k;
-        }
-        if (kmax > 0.f && std::isfinite(kmax)) {
-            constexpr int NB = 4096;
-            const float scale = (float)(NB - 1) / kmax;
-            std::vector<int64_t> start(NB + 1, 0);
-            std::vector<unsigned short> bin((size_t)n);
-            for (int64_t i = 0; i < n; i++) {
-                const float f = key[(size_t)i] * scale;
-                int b = (f >= 0.f && f < (float)NB) ? (int)f : 0;
-                b = NB - 1 - b;                                  // descending speed
-                bin[(size_t)i] = (unsigned short)b;
-                start[b + 1]++;
-            }
-            for (int b = 0; b < NB; b++) start[b + 1] += start[b];
-            std::vector<unsigned> order((size_t)n);
-            for (int64_t i = 0; i < n; i++) order[(size_t)start[bin[(size_t)i]]++] = (unsigned)i;
-            rc = ensure(reinterpret_cast<void **>(&h->d_order), &h->order_cap,
-                        (size_t)n * sizeof(unsigned));
-            if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(h->d_order, order.data(), (size_t)n * sizeof(unsigned),
-                                  hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            h->have_order = true;
-        }
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->n_packets = n;
-    h->first_id = 0;
-    h->rows_total = -1;
-    return NXC_OK;
-    });
-}
-
-// Device-side queue order (the same counting sort nxc_packets_upload does on the host).
+// Queue order of the resident packets, built on the device: counting sort of the packet indices
+// by decreasing |v|^2 (k_order_hist / k_order_scatter).  k2max: upper bound of |v|^2 when the
+// caller knows it (the sampler does), negative = find the largest finite |v|^2 on the device.
 static int order_on_device(nxc_handle *h, double k2max)
 {
     const int64_t n = h->n_packets;
     h->have_order = false;
+    if (n >= 2 && k2max < 0) {
+        unsigned long long bits = 0;
+        unsigned long long *d_max = reinterpret_cast<unsigned long long *>(h->d_reduce);
+        HIPCHK(hipMemsetAsync(d_max, 0, sizeof bits, h->stream));
+        hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+                           h->stream, h->d_packets, n, d_max);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::memcpy(&k2max, &bits, sizeof k2max);
+    }
     if (n < 2 || n >= (int64_t)0xffffffffll || !(k2max > 0) || !std::isfinite(k2max)) return NXC_OK;
     int rc = ensure(reinterpret_cast<void **>(&h->d_order), &h->order_cap, (size_t)n * sizeof(unsigned));
     if (rc) return rc;
@@ -945,6 +912,25 @@ static int order_on_device(nxc_handle *h, double k2max)
     return NXC_OK;
 }
 
+int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
+{
+    return guarded([&]() -> int {
+    if (!h || n < 0 || (n && !soa0)) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)8 * n * sizeof(double);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(h->d_packets, soa0, bytes, hipMemcpyHostToDevice, h->stream));
+    h->n_packets = n;
+    h->first_id = 0;
+    h->rows_total = -1;
+    // Queue order for the persistent kernels (longest-lived first): counting sort of the packet
+    // indices by decreasing |v|^2 on the device, bounded by the largest launch speed found there.
+    if ((rc = order_on_device(h, -1.0))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+    });
+}
 int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out)
 {
     return guarded([&]() -> int {
@@ -1372,7 +1358,15 @@ int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank
     if (h->comm) { g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof u);
-    NCCLCHK(g_rccl.CommInitRank(&h->comm, nranks, u, rank));
+    const ncclResult_t r = g_rccl.CommInitRank(&h->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        h->comm = nullptr;
+        if (r == ncclInvalidUsage || r == ncclInvalidArgument)
+            // what RCCL reports when two ranks of the communicator sit on one device
+            return fail(NXC_ERR_ARG, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r) +
+                                     " -- every rank needs its own GPU (one process per device)");
+        return fail(NXC_ERR_RCCL, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    }
     h->rank = rank;
     h->nranks = nranks;
     return NXC_OK;
@@ -1402,18 +1396,21 @@ int nxc_image_allreduce(nxc_handle *h)
     return NXC_OK;
 }
 
-int nxc_allreduce_max_f64(nxc_handle *h, double *value)
+static int allreduce_scalar(nxc_handle *h, double *value, ncclRedOp_t op)
 {
     if (!h || !value) return fail(NXC_ERR_ARG, "null argument");
     if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(h->d_reduce, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    NCCLCHK(g_rccl.AllReduce(h->d_reduce, h->d_reduce, 1, ncclFloat64, ncclMax, h->comm,
-                             h->stream));
+    NCCLCHK(g_rccl.AllReduce(h->d_reduce, h->d_reduce, 1, ncclFloat64, op, h->comm, h->stream));
     HIPCHK(hipMemcpyAsync(value, h->d_reduce, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
 }
+
+int nxc_allreduce_max_f64(nxc_handle *h, double *value) { return allreduce_scalar(h, value, ncclMax); }
+
+int nxc_allreduce_sum_f64(nxc_handle *h, double *value) { return allreduce_scalar(h, value, ncclSum); }
 
 int nxc_barrier(nxc_handle *h)
 {

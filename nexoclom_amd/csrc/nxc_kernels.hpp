@@ -739,6 +739,27 @@ NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t n, int64_t i, doub
     return NXC_ORDER_BINS - 1 - b;
 }
 
+// Largest finite |v|^2 of the resident packets (bit pattern of a non-negative double: its order
+// as an unsigned integer is its order as a number).
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_speed_max(const double *__restrict__ soa, int64_t n, unsigned long long *__restrict__ out)
+{
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double vx = soa[4 * n + i], vy = soa[5 * n + i], vz = soa[6 * n + i];
+        const double f = vx * vx + vy * vy + vz * vz;
+        if (f <= 1.7976931348623157e308 && f > m) m = f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0.0)
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+}
+
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_order_hist(const double *__restrict__ soa, int64_t n, double scale,
              unsigned long long *__restrict__ hist)

@@ -25,7 +25,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
            'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
-           'nxc_integrate_const_rows', 'nxc_rows_fetch')
+           'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_device_bus_id',
+           'nxc_allreduce_sum_f64')
 
 
 class HipError(RuntimeError):
@@ -160,6 +161,11 @@ class Context:
     def device_name(self):
         buf = C.create_string_buffer(256)
         self._check(self.lib.nxc_device_name(self._h, buf, C.c_int(256)))
+        return buf.value.decode()
+
+    def bus_id(self):
+        buf = C.create_string_buffer(64)
+        self._check(self.lib.nxc_device_bus_id(self._h, buf, C.c_int(64)))
         return buf.value.decode()
 
     def synchronize(self):
@@ -429,6 +435,11 @@ class Context:
     def allreduce_max(self, value):
         v = C.c_double(value)
         self._check(self.lib.nxc_allreduce_max_f64(self._h, C.byref(v)))
+        return float(v.value)
+
+    def allreduce_sum(self, value):
+        v = C.c_double(value)
+        self._check(self.lib.nxc_allreduce_sum_f64(self._h, C.byref(v)))
         return float(v.value)
 
     def barrier(self):

@@ -1,58 +1,102 @@
-"""N > 1 logic on CPU: two gloo ranks shard the packets by index, each integrates its shard (the
-C oracle stands in for the GPU kernel here), and the summed image pair equals the single-rank
-result -- counts exactly, weights to fp64 summation order.  Also exercises the ControlPlane
-primitives bench.py uses (barrier, MAX/SUM, unique-id broadcast)."""
+"""N > 1 logic on CPU, world_size 2, through the PRODUCT's own partition and merge code:
+nexoclom_amd.distributed.sharded_image -> ModelImage._stream (chunk grid, per-chunk seeds, row
+slices) -> merge_shards -> finalize.  The only stand-in is the device (tests/oracle_context.py:
+the C oracle answers the Context calls).  For BOTH samplers the 2-rank result must equal the
+1-rank result: packet-count image and totals exactly, weights to fp64 summation order.  Runs once
+over the product's TCP control plane and once over torch.distributed gloo."""
+import multiprocessing as mp
 import os
 import sys
 
 import numpy as np
-import torch.multiprocessing as mp
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INPUT = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
+PARAMS = {'quantity': 'radiance', 'dims': '64,64', 'width': '8,8'}
+N, SEED, CHUNK = 1201, 2024, 500          # 3 chunks; the shard boundary 601 falls inside chunk 1
 
 
-def _worker(rank, world, port, tmpdir):
+def _plane(kind, world, rank):
+    if kind == 'gloo':
+        from tests.gloo_plane import GlooControlPlane
+        return GlooControlPlane(world, rank)
+    from nexoclom_amd.distributed import ControlPlane
+    return ControlPlane(world, rank, timeout=120)
+
+
+def _worker(rank, world, port, tmpdir, kind):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from nexoclom_amd.distributed import ControlPlane, shard_range
-    from oracle import np_oracle as O
-    from oracle.c_oracle import COracle
-    from tests import helpers as H
-    cp = ControlPlane()
+    import contextlib
+    import io
+    from nexoclom_amd import Input
+    from nexoclom_amd.distributed import ControlPlane, sharded_image
+    from tests.oracle_context import OracleContext
+    cp = _plane(kind, world, rank)
     assert cp.world == world and cp.rank == rank
     cp.barrier()
     assert cp.reduce(rank + 1.0, 'MAX') == world
     assert cp.reduce(rank + 1.0, 'SUM') == world*(world+1)/2
+    assert cp.reduce(rank + 1.0, 'MIN') == 1.0
     payload = bytes(range(128)) if rank == 0 else b''
     assert cp.bcast_bytes(payload, 128) == bytes(range(128))
+    assert cp.allgather_bytes(b'r%d' % rank) == [b'r%d' % r for r in range(world)]
 
-    n = 3001                                     # not divisible by the world size
-    f = H.mercury_forces('Na', 1.3)
-    X0 = H.sample_x0(n, 2024, 50000.)            # every rank draws the same global X0
-    lo, hi = shard_range(n, rank, world)
-    nsteps, n_iter = O.n_output_steps(50000., 30.)
-    co = COracle()
-    im = H.image_setup(f, 'radiance', dims=(64, 64))
-    desc = co.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
-                         im['xedges'], im['zedges'], downcast=True)
-    part = co.integrate_const(f, X0[lo:hi], 30., n_iter, 25., img=desc)
-    image, counts = cp.allreduce_images_host(part['image'], part['counts'])
-    work = cp.reduce(part['work'], 'SUM')
-    if rank == 0:
-        full = co.integrate_const(f, X0, 30., n_iter, 25., img=desc)
-        assert work == full['work']
-        assert np.array_equal(counts, full['counts'])
-        np.testing.assert_allclose(image, full['image'], rtol=1e-12)
-        open(os.path.join(tmpdir, 'ok'), 'w').write('ok')
+    inputs = Input(INPUT)
+    for sampler in ('numpy', 'device'):
+        ctx = OracleContext()
+        with contextlib.redirect_stdout(io.StringIO()):
+            part = sharded_image(inputs, PARAMS, N, SEED, cp=cp, context=ctx, sampler=sampler,
+                                 packs_per_it=CHUNK, reduce='host')
+        # this rank integrated only its own rows, addressed by their GLOBAL index
+        want = [(500, 0), (101, 500)] if rank == 0 else [(399, 601), (201, 1000)]
+        assert ctx.calls == want, (sampler, rank, ctx.calls)
+        if rank == 0:
+            one = OracleContext()
+            with contextlib.redirect_stdout(io.StringIO()):
+                whole = sharded_image(inputs, PARAMS, N, SEED, cp=ControlPlane(1, 0), context=one,
+                                      sampler=sampler, packs_per_it=CHUNK, reduce='host')
+            assert one.calls == [(500, 0), (500, 500), (201, 1000)]
+            assert whole.npackets == part.npackets == N
+            assert whole.totalsource == part.totalsource == N*1668
+            assert whole.atoms_per_packet == part.atoms_per_packet
+            assert whole.packet_image.sum() > 1000
+            assert np.array_equal(whole.packet_image, part.packet_image), sampler
+            np.testing.assert_allclose(part.image, whole.image, rtol=1e-12, atol=0)
+            np.save(os.path.join(tmpdir, f'{sampler}.npy'), part.packet_image)
     cp.barrier()
     cp.close()
+    if rank == 0:
+        # the two samplers draw different packets: the images must not be the same array
+        a, b = (np.load(os.path.join(tmpdir, f'{s}.npy')) for s in ('numpy', 'device'))
+        assert not np.array_equal(a, b)
+        open(os.path.join(tmpdir, 'ok'), 'w').write('ok')
 
 
-def test_two_rank_sharding_and_image_sum(tmp_path):
-    port = 29500 + os.getpid() % 400
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+def _run(kind, tmp_path, world=2):
+    port = 29500 + os.getpid() % 400 + (17 if kind == 'gloo' else 0)
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), kind))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert (tmp_path / 'ok').exists()
+
+
+def test_two_ranks_equal_one_rank_over_the_tcp_control_plane(tmp_path):
+    _run('tcp', tmp_path)
+
+
+def test_two_ranks_equal_one_rank_over_gloo(tmp_path):
+    _run('gloo', tmp_path)
 
 
 def test_shard_ranges_cover_everything():
@@ -64,3 +108,28 @@ def test_shard_ranges_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_chunk_plan_is_independent_of_the_shard_count():
+    """The union over ranks of the per-rank pieces is the single-rank chunk loop, every global
+    index exactly once, each piece inside one chunk."""
+    from nexoclom_amd.distributed import chunk_plan, shard_range
+    for total, chunk in ((0, 5), (1, 5), (23, 5), (25, 5), (1201, 500), (10, 100)):
+        whole = list(chunk_plan(total, chunk))
+        assert [(c0, clen) for _, c0, clen, _, _ in whole] == \
+            [(c0, min(chunk, total - c0)) for c0 in range(0, total, chunk)]
+        assert all(a == c0 and b == c0 + clen for _, c0, clen, a, b in whole)
+        for world in (1, 2, 3, 8):
+            seen = np.zeros(total, dtype=int)
+            for r in range(world):
+                lo, hi = shard_range(total, r, world)
+                for k, c0, clen, a, b in chunk_plan(total, chunk, lo, hi):
+                    assert c0 == k*chunk and c0 <= a < b <= c0 + clen and lo <= a and b <= hi
+                    seen[a:b] += 1
+            assert (seen == 1).all()
+
+
+def test_control_plane_refuses_a_missing_rank_zero(tmp_path):
+    from nexoclom_amd.distributed import ControlPlane
+    with pytest.raises(TimeoutError):
+        ControlPlane(2, 1, timeout=0.3, rendezvous=str(tmp_path / 'nobody.addr'))

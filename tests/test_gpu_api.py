@@ -330,20 +330,47 @@ def test_output_files_round_trip(ctx, tmp_path):
     np.testing.assert_allclose(image*mem.atoms_per_packet, mem.image, rtol=1e-12)
 
 
-def test_sharded_image_is_independent_of_the_shard_count(ctx):
-    """Multi-GPU semantics on one GPU: the image of N device-sampled packets equals the sum of
-    the images of its index shards (what nexoclom_amd.distributed.sharded_image reduces over
-    RCCL), packet counts exactly -- i.e. 1, 2 or 8 GPUs give the same image."""
+@pytest.mark.parametrize('sampler', ['device', 'numpy'])
+def test_sharded_image_is_independent_of_the_shard_count(ctx, sampler):
+    """Multi-GPU semantics on one GPU: the image of N packets equals the sum of the images of its
+    index shards (what nexoclom_amd.distributed.sharded_image reduces over RCCL), packet counts
+    exactly -- i.e. 1, 2 or 8 GPUs give the same image -- for the counter-based device sampler
+    and for the host sampler (fixed chunk grid, chunk k drawn from seed + k, rows sliced)."""
     from nexoclom_amd.distributed import ControlPlane, shard_range, sharded_image
     inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
     params = {'quantity': 'radiance', 'dims': '128,128'}
-    whole = sharded_image(inputs, params, 9001, seed=42, cp=ControlPlane(world=1, rank=0), device=0)
+    whole = sharded_image(inputs, params, 9001, seed=42, cp=ControlPlane(world=1, rank=0),
+                          context=ctx, sampler=sampler, packs_per_it=4000)
     image = np.zeros((128, 128)); counts = np.zeros((128, 128)); total = 0.
     for rank in range(3):
         lo, hi = shard_range(9001, rank, 3)
-        part = ModelImage(inputs, params, npackets=hi - lo, seed=42, context=ctx,
-                          sampler='device', first_index=lo, finalize=False)
+        part = ModelImage(inputs, params, npackets=9001, shard=(lo, hi), seed=42, context=ctx,
+                          sampler=sampler, packs_per_it=4000, finalize=False)
+        assert part.npackets == hi - lo
         image += part.image; counts += part.packet_image; total += part.totalsource
     assert total == whole.totalsource == 9001*1668
+    assert counts.sum() > 1e5
     assert np.array_equal(counts, whole.packet_image)
     np.testing.assert_allclose(image*whole.atoms_per_packet, whole.image, rtol=1e-11)
+    # and the un-sharded streaming ModelImage is that same image
+    plain = ModelImage(inputs, params, npackets=9001, seed=42, context=ctx, sampler=sampler,
+                       packs_per_it=4000)
+    assert np.array_equal(plain.packet_image, whole.packet_image)
+
+
+def test_rccl_refuses_two_ranks_on_one_device(ctx):
+    """Two communicator ranks on one GPU is what a mis-launched job looks like; the control plane
+    reports it before RCCL is asked (and names the device), instead of timing a fallback."""
+    from nexoclom_amd import hip_api
+    from nexoclom_amd.distributed import ControlPlane
+
+    class TwoOnOne(ControlPlane):          # a 2-rank world whose ranks share this process's GPU
+        def __init__(self):
+            super().__init__(world=1, rank=0)
+            self.world = 2
+
+        def allgather_bytes(self, payload):
+            return [payload, payload]
+    with pytest.raises(hip_api.HipError, match='one process per GPU'):
+        TwoOnOne().init_rccl(ctx)
+    assert len(ctx.bus_id()) >= 7
