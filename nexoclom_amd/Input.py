@@ -1,19 +1,46 @@
 """Input: the inputfile-driven front door of a model run.
 
-Mirrors the reference's initial_state/Input.py:27-272: ``Input(infile)`` parses
-``category.parameter = value`` lines (';' / '#' comments, case-folded keys, exactly one '=' and
-one '.', Input.py:60-80) into the seven spec objects; ``run()`` integrates packets in chunks;
-``search()`` reports what has been run; ``produce_image()`` builds a ModelImage.  The PostgreSQL
-catalogue of the reference is replaced by an in-memory list of Output objects on the Input (plus
-optional .npz files under ``savepath``).
+Drop-in for the reference's initial_state/Input.py:27-272 on the hot path: ``Input(infile)`` turns
+the ``section.key = value`` lines of an inputfile into seven section objects (``geometry``,
+``surfaceinteraction``, ``forces``, ``spatialdist``, ``speeddist``, ``angulardist``,
+``options``); ``run()`` integrates packets chunk by chunk; ``search()`` tells what has been run;
+``produce_image()`` builds a ModelImage.  The file grammar is the reference's (Input.py:60-80): a
+``;`` -- or, on lines without one, a ``#`` -- starts a comment; a line counts only if it holds
+exactly one ``=`` and the left side exactly one ``.``; section and key are case-folded.
+
+The reference catalogues runs in PostgreSQL; here the catalogue is the list of Output objects kept
+on the Input (plus optional .npz files under ``savepath``).
 """
+import math
 import os
 import time
 
-import numpy as np
+from . import input_classes as spec
 
-from .input_classes import (AngularDist, Forces, Geometry, Options, SpatialDist, SpeedDist,
-                            SurfaceInteraction)
+# section name in the file -> (attribute on the Input, class that interprets it)
+SECTIONS = (('geometry', spec.Geometry), ('surfaceinteraction', spec.SurfaceInteraction),
+            ('forces', spec.Forces), ('spatialdist', spec.SpatialDist),
+            ('speeddist', spec.SpeedDist), ('angulardist', spec.AngularDist),
+            ('options', spec.Options))
+
+
+def read_inputfile(path):
+    """{section: {key: value text}} of an inputfile; later lines override earlier ones."""
+    if not os.path.isfile(path):
+        raise FileNotFoundError(path)
+    table = {}
+    with open(path, 'r') as handle:
+        for raw in handle:
+            mark = ';' if ';' in raw else '#'
+            text = raw.split(mark, 1)[0]
+            left, eq, right = text.partition('=')
+            if not eq or '=' in right:
+                continue
+            section, dot, key = left.partition('.')
+            if not dot or '.' in key:
+                continue
+            table.setdefault(section.casefold().strip(), {})[key.casefold().strip()] = right.strip()
+    return table
 
 
 class Input:
@@ -22,48 +49,20 @@ class Input:
         self.savepath = savepath
         self._catalogue = []          # Output objects run with these inputs
         self._fused = []              # fused integrate+image results (ModelImage streaming mode)
-        params = []
-        if os.path.isfile(infile):
-            for line in open(infile, 'r'):
-                if ';' in line:
-                    line = line[:line.find(';')]
-                elif '#' in line:
-                    line = line[:line.find('#')]
-                if line.count('=') == 1:
-                    param_, val_ = line.split('=')
-                    if param_.count('.') == 1:
-                        sec_, par_ = param_.split('.')
-                        params.append((sec_.casefold().strip(), par_.casefold().strip(),
-                                       val_.strip()))
-        else:
-            raise FileNotFoundError(infile)
+        table = read_inputfile(infile)
+        for name, cls in SECTIONS:
+            setattr(self, name, cls(table.get(name, {})))
 
-        def extract_param(tag):
-            return {b: c for (a, b, c) in params if a == tag}
-
-        self.geometry = Geometry(extract_param('geometry'))
-        self.surfaceinteraction = SurfaceInteraction(extract_param('surfaceinteraction'))
-        self.forces = Forces(extract_param('forces'))
-        self.spatialdist = SpatialDist(extract_param('spatialdist'))
-        self.speeddist = SpeedDist(extract_param('speeddist'))
-        self.angulardist = AngularDist(extract_param('angulardist'))
-        self.options = Options(extract_param('options'))
+    def _sections(self):
+        return [getattr(self, name) for name, _ in SECTIONS]
 
     def __eq__(self, other):
-        if not isinstance(other, type(self)):
-            return False
-        return all([self.geometry == other.geometry,
-                    self.surfaceinteraction == other.surfaceinteraction,
-                    self.forces == other.forces,
-                    self.spatialdist == other.spatialdist,
-                    self.speeddist == other.speeddist,
-                    self.angulardist == other.angulardist,
-                    self.options == other.options])
+        return isinstance(other, type(self)) and self._sections() == other._sections()
+
+    __hash__ = None
 
     def __str__(self):
-        return '\n'.join(str(s) for s in (self.geometry, self.surfaceinteraction, self.forces,
-                                          self.spatialdist, self.speeddist, self.angulardist,
-                                          self.options))
+        return '\n'.join(str(section) for section in self._sections())
 
     __repr__ = __str__
 
@@ -71,69 +70,75 @@ class Input:
     def search(self):
         """(ids, outputs-or-filenames, npackets, totalsource) of the runs made with these inputs
         (Input.py:121-172, without the database)."""
-        if not self._catalogue:
+        runs = self._catalogue
+        if not runs:
             return [], [], 0, 0
-        ids = [o.idnum for o in self._catalogue]
-        files = [o.filename if o.filename else o for o in self._catalogue]
-        return (ids, files, int(sum(o.npackets for o in self._catalogue)),
-                float(sum(o.totalsource for o in self._catalogue)))
+        return ([run.idnum for run in runs], [run.filename or run for run in runs],
+                int(sum(run.npackets for run in runs)),
+                float(sum(run.totalsource for run in runs)))
 
     def delete_files(self, filename=None):
-        keep = []
-        for o in self._catalogue:
-            if filename is None or o.filename == filename:
-                if o.filename and os.path.exists(o.filename):
-                    os.remove(o.filename)
-            else:
-                keep.append(o)
-        self._catalogue = keep
+        """Forget (and remove from disk) every catalogued run, or only the one saved as
+        ``filename`` (Input.py:274-...)."""
+        doomed = [run for run in self._catalogue if filename is None or run.filename == filename]
+        for run in doomed:
+            if run.filename and os.path.exists(run.filename):
+                os.remove(run.filename)
+        self._catalogue = [run for run in self._catalogue if run not in doomed]
         self._fused = []
 
     def chunk_size(self, packs_per_it=None):
-        """Packets per Output (Input.py:216-227): 1e6 in variable-step mode, else
-        ceil(1024^3 / nsteps / 8)."""
-        if (packs_per_it is None) and (self.options.step_size == 0):
-            packs_per_it = 1000000
-        elif packs_per_it is None:
-            nsteps = int(np.ceil(self.options.endtime.value / self.options.step_size) + 1)
-            packs_per_it = np.ceil(1024**3 / nsteps / 8)
-        return int(packs_per_it)
+        """Packets per Output when the caller does not say (Input.py:216-227): a million for the
+        adaptive driver; for the constant-step driver as many as keep the (N, 8, nsteps) history
+        near 1024^3 doubles / 8."""
+        if packs_per_it is not None:
+            return int(packs_per_it)
+        step = self.options.step_size
+        if step == 0:
+            return 1_000_000
+        records = int(math.ceil(self.options.endtime.value/step) + 1)
+        return int(math.ceil(1024**3/records/8))
 
     def run(self, npackets, packs_per_it=None, overwrite=False, compress=True,
             distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None):
-        """Run the model (Input.py:175-268).  Each chunk is one Output.  A given ``seed`` seeds
-        chunk k with ``seed + k`` -- chunk 0 is the reference's stream; the reference itself
-        re-uses the same seed for every chunk (Input.py:246), which repeats identical packets."""
+        """Integrate until the catalogue holds ``npackets`` packets (Input.py:175-268).
+
+        Every pass plans ``ceil(todo / size)`` Outputs of ``size = min(todo, chunk_size)``
+        packets -- the reference's arithmetic, so the last Output of a pass may overshoot.  With a
+        ``seed`` the k-th Output of this call is drawn from ``seed + k``: Output 0 is the
+        reference's stream; the reference itself passes the same seed to every Output
+        (Input.py:246), which repeats identical packets."""
         from .Output import Output
-        t0 = time.time()
-        distribute = distribute in (True, 'delay', 'delayed')
+        started = time.time()
+        if distribute in (True, 'delay', 'delayed'):
+            assert False, 'Dont do this'         # the reference's dask path is disabled too
         if overwrite:
             self.delete_files()
-            totalpackets = 0
-        else:
-            _, outputfiles, totalpackets, _ = self.search()
-            print(f'Found {len(outputfiles)} files with {totalpackets} packets.')
-        npackets = int(npackets)
-        ntodo = npackets - totalpackets
-        chunk = 0
-        while ntodo > 0:
-            per_it = int(np.min([ntodo, self.chunk_size(packs_per_it)]))
-            nits = int(np.ceil(ntodo/per_it))
+        have = self._report()
+        want = int(npackets)
+        made = 0
+        while have < want:
+            todo = want - have
+            size = min(todo, self.chunk_size(packs_per_it))
+            passes = -(-todo // size)
             print('Running Model')
-            print(f'Will complete {nits} iterations of {per_it} packets.')
-            if distribute:
-                assert False, 'Dont do this'
-            for it in range(nits):
-                print(f'Starting iteration #{it+1} of {nits}')
-                out = Output(self, per_it, compress=compress,
-                             seed=None if seed is None else seed + chunk, device=device,
+            print(f'Will complete {passes} iterations of {size} packets.')
+            for number in range(1, passes + 1):
+                print(f'Starting iteration #{number} of {passes}')
+                tick = time.time()
+                out = Output(self, size, compress=compress,
+                             seed=None if seed is None else seed + made, device=device,
                              keep_trajectory=keep_trajectory, context=context)
-                context = out.context()
-                chunk += 1
-            _, outputfiles, totalpackets, _ = self.search()
-            print(f'Found {len(outputfiles)} files with {totalpackets} packets.')
-            ntodo = npackets - totalpackets
-        print(f'Model run completed in {time.time()-t0:.2f} sec.')
+                context = out.context()          # every Output of the run shares one device
+                made += 1
+                print(f'Completed iteration #{number} in {time.time() - tick} seconds.')
+            have = self._report()
+        print(f'Model run completed in {time.time() - started:.2f} sec.')
+
+    def _report(self):
+        _, files, packets, _ = self.search()
+        print(f'Found {len(files)} files with {packets} packets.')
+        return packets
 
     def produce_image(self, format_, overwrite=False, distribute=None, **kwargs):
         from .ModelImage import ModelImage

@@ -1,150 +1,165 @@
-"""g-values, radiation acceleration and photo-loss rates (host side; tables feed the kernels).
+"""g-values, radiation acceleration and photo-loss rates (host side; the tables feed the kernels).
 
-Re-statement without astropy/periodictable of the reference's
-  atomicdata/g_values.py:59-94      gValue        g(v) for one line, scaled (r_ref/a)^2, sorted by v
-  atomicdata/g_values.py:134-160    RadPresConst  a_rad(v) = sum_lines h/(m lambda) g_line(v)
-  atomicdata/photolossrates.py:66-86 PhotoRate    sum of kappa/a^2 over ALL reactions of a species
-  atomicdata/atomicmass.py:5-51     atomicmass
-The tables come from nexoclom_amd/data/*.csv (built by tools/make_data.py from the reference's
-text data files).
+Drop-in, without astropy / periodictable / pandas pickles, for the reference's
+  atomicdata/g_values.py:59-94       gValue        g(v) of one line, scaled (r_ref/a)^2, sorted by v
+  atomicdata/g_values.py:134-160     RadPresConst  a_rad(v) = sum over lines of h/(m lambda) g(v)
+  atomicdata/photolossrates.py:66-86 PhotoRate     sum of kappa/a^2 over ALL reactions of a species
+  atomicdata/atomicmass.py:5-51      atomicmass
+  initial_state/LossInfo.py:5-35     LossInfo
+
+Data: nexoclom_amd/data/gvalues.csv and photorates.csv, written by tools/make_data.py from the
+reference's TEXT data files with 17 significant digits.  They are parsed here with Python's
+correctly rounded ``float`` into one in-memory index per file -- {(species, wavelength): line} and
+{species: reactions} -- built on first use, so the doubles are exactly the ones make_data wrote
+and a lookup is a dict access, not a table scan.
 """
+import csv
 import functools
 import os
+from collections import namedtuple
 
 import numpy as np
-import pandas as pd
 
 from . import constants as const
 from .units import Quantity
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
 
-
-@functools.lru_cache(maxsize=None)
-def _gvalue_table():
-    return pd.read_csv(os.path.join(_DATA, 'gvalues.csv'))
+Line = namedtuple('Line', 'velocity gvalue refpoint sources')       # arrays in file order
+Reaction = namedtuple('Reaction', 'reaction kappa reference')
 
 
 @functools.lru_cache(maxsize=None)
-def _photo_table():
-    return pd.read_csv(os.path.join(_DATA, 'photorates.csv'))
+def _lines():
+    """{(species, wavelength): Line} plus, under the key species, its wavelengths."""
+    rows = {}
+    with open(os.path.join(_DATA, 'gvalues.csv'), newline='') as handle:
+        for row in csv.DictReader(handle):
+            key = (row['species'], float(row['wavelength']))
+            rows.setdefault(key, []).append((float(row['velocity']), float(row['gvalue']),
+                                             float(row['refpoint']), row['source']))
+    index = {}
+    for (species, wavelength), recs in rows.items():
+        v, g, ref, src = zip(*recs)
+        index[(species, wavelength)] = Line(np.array(v), np.array(g), np.array(ref),
+                                            tuple(dict.fromkeys(src)))
+        index.setdefault(species, []).append(wavelength)
+    return index
+
+
+@functools.lru_cache(maxsize=None)
+def _reactions():
+    table = {}
+    with open(os.path.join(_DATA, 'photorates.csv'), newline='') as handle:
+        for row in csv.DictReader(handle):
+            table.setdefault(row['species'], []).append(
+                Reaction(row['reaction'], float(row['kappa']), row['reference']))
+    return table
 
 
 def atomicmass(species):
     """Atomic mass in u (atomicdata/atomicmass.py:5-51); None when unknown."""
-    if species in const.ATOMIC_MASS:
-        return Quantity(const.ATOMIC_MASS[species], 'u')
-    print(f'WARNING: mathMB.atomicmass: {species} not found')
-    return None
+    mass = const.ATOMIC_MASS.get(species)
+    if mass is None:
+        print(f'WARNING: mathMB.atomicmass: {species} not found')
+        return None
+    return Quantity(mass, 'u')
 
 
-def _au(aplanet):
-    return float(aplanet)
+def _flat_table():
+    """The reference's answer for an unknown species or line: two points, all zero."""
+    return np.array([0., 1.]), np.array([0., 0.])
 
 
 class gValue:
-    """g-value vs. radial velocity for (species, wavelength) at heliocentric distance aplanet.
-
-    ``velocity`` [km/s] ascending, ``g`` [1/s] (atomicdata/g_values.py:75-91).  Unknown
-    species/line gives the reference's two-point zero table (:78-83).
-    """
+    """g-value [1/s] vs. radial velocity [km/s] of one emission line at heliocentric distance
+    ``aplanet`` [au]: the tabulated values times (reference distance / aplanet)^2, ascending in
+    velocity (atomicdata/g_values.py:75-91)."""
 
     def __init__(self, sp, wavelength, aplanet=1.0):
         self.species = sp
         self.wavelength = Quantity(float(wavelength), 'AA')
-        self.aplanet = Quantity(_au(aplanet), 'au')
-        tab = _gvalue_table()
-        gvalue = tab[(tab.species == sp) & (tab.wavelength == float(wavelength))]
-        if len(gvalue) == 0:
-            self.velocity = np.array([0., 1.])
-            self.g = np.array([0., 0.])
+        self.aplanet = Quantity(float(aplanet), 'au')
+        line = _lines().get((sp, float(wavelength)))
+        if line is None:
+            self.velocity, self.g = _flat_table()
             self.filename = None
             print(f'Warning: g-values not found for species = {sp}')
-        elif len(gvalue.source.unique()) == 1:
-            velocity = gvalue.velocity.values.astype(float)
-            g = (gvalue.gvalue * gvalue.refpoint**2 / self.aplanet.value**2).values
-            s = np.argsort(velocity)
-            self.velocity, self.g = velocity[s], g[s]
-            self.filename = gvalue.source.unique()[0]
-        else:
+            return
+        if len(line.sources) != 1:
             print('This should never happen')
             raise ValueError()
+        order = np.argsort(line.velocity)
+        self.velocity = line.velocity[order]
+        self.g = (line.gvalue * line.refpoint**2 / self.aplanet.value**2)[order]
+        self.filename = line.sources[0]
 
 
 class RadPresConst:
-    """Radiation acceleration vs. radial velocity (atomicdata/g_values.py:134-160).
-
-    ``velocity`` [km/s] = sorted union of all the species' g-value velocity grids (:146);
-    ``accel`` [km/s^2] = sum over the species' lines of h/(m lambda) * interp(g_line) (:150-154).
-    """
+    """Radiation acceleration [km/s^2] vs. radial velocity [km/s] of a species
+    (atomicdata/g_values.py:134-160): every line's g(v) is interpolated onto the sorted union of
+    the species' velocity grids and contributes h / (m lambda) g."""
 
     def __init__(self, species, aplanet):
         self.species = species
-        self.aplanet = Quantity(_au(aplanet), 'au')
-        tab = _gvalue_table()
-        if species in tab.species.values:
-            subset = tab.loc[tab.species == species]
-            self.wavelength = np.array(sorted(subset.wavelength.unique()))
-            self.velocity = np.array(sorted(subset.velocity.unique()))
-            rpres = np.zeros_like(self.velocity)
-            mass_kg = atomicmass(species).value * const.AMU
-            for wave in self.wavelength:
-                gval = gValue(species, wave, aplanet)
-                g_ = np.interp(self.velocity, gval.velocity, gval.g)
-                # h / m / lambda * g  [m/s^2] -> km/s^2
-                rpres_ = const.H_PLANCK / mass_kg / (wave * 1e-10) * g_
-                rpres += rpres_ * 1e-3
-            self.accel = rpres
-        else:
-            self.velocity = np.array([0., 1.])
-            self.accel = np.array([0., 0.])
+        self.aplanet = Quantity(float(aplanet), 'au')
+        waves = _lines().get(species)
+        if not waves:
+            self.velocity, self.accel = _flat_table()
             print(f'Warning: g-values not found for species = {species}')
+            return
+        self.wavelength = np.array(sorted(waves))
+        self.velocity = np.unique(np.concatenate([_lines()[(species, w)].velocity for w in waves]))
+        mass_kg = atomicmass(species).value * const.AMU
+        total = np.zeros_like(self.velocity)
+        for wave in self.wavelength:
+            line = gValue(species, wave, aplanet)
+            on_grid = np.interp(self.velocity, line.velocity, line.g)
+            momentum_kick = const.H_PLANCK / mass_kg / (wave * 1e-10) * on_grid      # m/s^2
+            total += momentum_kick * 1e-3
+        self.accel = total
 
 
 class PhotoRate:
-    """Total photo-loss rate [1/s] of a species at aplanet [au] (photolossrates.py:66-86)."""
+    """Total photo-loss rate [1/s] of a species at ``aplanet_`` [au]: every tabulated reaction of
+    the species counts, each scaled 1/a^2 (photolossrates.py:66-86)."""
 
     def __init__(self, species, aplanet_=1.0):
-        tab = _photo_table()
-        prates = tab[tab.species == species]
-        aplanet = _au(aplanet_)
+        aplanet = float(aplanet_)
         self.species = species
         self.aplanet = Quantity(aplanet, 'au')
-        if len(prates) == 0:
+        found = _reactions().get(species)
+        if not found:
             print('No photoreactions found')
             self.reactions = None
             self.rate = Quantity(1e-30, '1/s')
-        else:
-            rates = prates['kappa'].apply(lambda k: k/aplanet**2).values
-            self.reactions = prates
-            self.rate = Quantity(rates.sum(), '1/s')
+            return
+        self.reactions = found
+        self.rate = Quantity(np.array([r.kappa/aplanet**2 for r in found]).sum(), '1/s')
 
     def __str__(self):
-        return (f'Species = {self.species}\nDistance = {self.aplanet}\nRate = {self.rate}')
+        return f'Species = {self.species}\nDistance = {self.aplanet}\nRate = {self.rate}'
 
 
 class LossInfo:
-    """Loss processes for a run (initial_state/LossInfo.py:5-35): photo = |1/lifetime| for a
-    negative lifetime, PhotoRate(species, aplanet) for lifetime == 0."""
+    """What removes atoms during a run (initial_state/LossInfo.py:5-35): a negative lifetime
+    means a generic photo-process of rate 1/|lifetime|; lifetime 0 means the tabulated
+    photo-reactions of the species at the planet's distance."""
 
     def __init__(self, atom, lifetime, aplanet):
-        self.photo = 0.
-        self.eimp = 0.
-        self.chX = 0.
-        self.reactions = []
-        lifetime_ = float(lifetime)
-        if lifetime_ < 0:
-            self.photo = np.abs(1./lifetime_)
-            self.reactions = 'Generic photo reaction'
-        elif lifetime_ == 0:
-            photo = PhotoRate(atom, aplanet)
-            self.photo = photo.rate.value
-            self.reactions = (photo.reactions['reaction'].values
-                              if photo.reactions is not None else [])
-        else:
+        self.photo, self.eimp, self.chX = 0., 0., 0.
+        self.reactions = None
+        lifetime = float(lifetime)
+        if lifetime > 0:
             print('LossInfo objects should not be instantiated with lifetime > 0')
-        if len(self.reactions) == 0:
-            self.reactions = None
+        elif lifetime < 0:
+            self.photo = abs(1./lifetime)
+            self.reactions = 'Generic photo reaction'
+        else:
+            tabulated = PhotoRate(atom, aplanet)
+            self.photo = tabulated.rate.value
+            names = [r.reaction for r in (tabulated.reactions or ())]
+            self.reactions = np.array(names) if names else None
 
     def __len__(self):
-        return len(self.reactions) if self.reactions is not None else 0
+        return 0 if self.reactions is None else len(self.reactions)

@@ -1,22 +1,31 @@
-"""The seven specification classes an Input holds (parser side only).
+"""The seven sections of an inputfile as declarative specifications.
 
-Same names, attributes, defaults, clamping rules and error behaviour as the constructors in the
-reference's initial_state/input_classes.py (Geometry :19-111, SurfaceInteraction :250-318,
-Forces :419-431, SpatialDist :490-569, SpeedDist :702-761, AngularDist :905-960, Options
-:1055-1100).  The PostgreSQL ``insert()``/``search()`` methods of the reference are out of scope
-(SURVEY.md section 8b); the run catalogue lives in nexoclom_amd.Input instead.  Quantities are
-nexoclom_amd.units.Quantity (float with .value) instead of astropy.
+The reference builds each section object with a hand-written constructor
+(initial_state/input_classes.py: Geometry :19-111, SurfaceInteraction :250-318, Forces :419-431,
+SpatialDist :490-569, SpeedDist :702-761, AngularDist :905-960, Options :1055-1100).  Here a
+section is DATA: a tuple of ``Field`` records -- attribute name, accepted keys, a text -> value
+converter, a default or the error raised when the key is missing -- optionally switched by the
+section's ``type`` key, and one generic ``Section.__init__`` walks it.  What is kept from the
+reference is the contract a drop-in needs: class names, attribute names and their order in
+``__dict__``, defaults, clamping rules, which omissions raise ``InputError`` (and with which
+text), equality and the ``section.key = value`` rendering.
+
+Not here: the PostgreSQL ``insert()`` / ``search()`` methods (out of scope, SURVEY.md section 8b;
+the run catalogue lives on nexoclom_amd.Input) and astropy -- quantities are
+nexoclom_amd.units.Quantity (a float that answers ``.value`` / ``.unit``).
 """
+import math
 import os
-
-import numpy as np
 
 from .solarsystem import SSObject
 from .units import Quantity
 
+TWO_PI = 2*math.pi
+HALF_PI = math.pi/2
+
 
 class InputError(Exception):
-    """Raised when a required parameter is not included (utilities/exceptions.py:2-6)."""
+    """A required parameter is missing or malformed (utilities/exceptions.py:2-6)."""
 
     def __init__(self, expression, message):
         self.expression = expression
@@ -24,339 +33,357 @@ class InputError(Exception):
         super().__init__(expression, message)
 
 
-class _Spec:
-    _prefix = ''
-
-    def __eq__(self, other):
-        if not isinstance(other, type(self)):
-            return False
-        if set(self.__dict__) != set(other.__dict__):
-            return False
-        return all(self.__dict__[k] == other.__dict__[k] for k in self.__dict__)
-
-    def __str__(self):
-        return '\n'.join(f'{self._prefix}.{k} = {v}' for k, v in self.__dict__.items())
-
-    __repr__ = __str__
+# ---- converters: the text right of '=' -> attribute value ---------------------------------------
+def number(text):
+    return float(text)
 
 
-def _rad(v):
-    return Quantity(v, 'rad')
+def measured(unit):
+    """float with a unit label."""
+    return lambda text: Quantity(float(text), unit)
 
 
-class Geometry(_Spec):
-    _prefix = 'geometry'
-
-    def __init__(self, gparam):
-        planet = gparam.get('planet', None)
-        if planet is None:
-            raise InputError('Geometry.__init__', 'Planet not defined in inputfile.')
-        self.planet = SSObject(planet.title())
-
-        objlist = [self.planet.object]
-        if self.planet.moons is not None:
-            objlist.extend([m.object for m in self.planet.moons])
-
-        self.startpoint = gparam.get('startpoint', self.planet.object).title()
-        if self.startpoint not in objlist:
-            print(f'{self.startpoint} is not a valid starting point.')
-            olist = '\n\t'.join(objlist)
-            print(f'Valid choices are:\n\t{olist}')
-            raise ValueError
-
-        if 'objects' in gparam:
-            inc = set(i.strip().title() for i in gparam['objects'].split(','))
-        else:
-            inc = {self.planet.object, self.startpoint}
-        for i in inc:
-            if i not in objlist:
-                raise InputError('Geometry.__init__', f'Invalid object {i} in geometry.include')
-        self.objects = set(SSObject(o) for o in inc)
-        if len(self.objects) == 0:
-            self.objects = None
-
-        if 'starttime' in gparam:
-            self.type = 'geometry with starttime'
-            # The reference parses an astropy Time here; only the string is kept (SPICE-based
-            # geometry is out of scope and Output refuses this type, Output.py:95-96).
-            self.time = gparam['starttime'].upper()
-        else:
-            self.type = 'geometry without starttime'
-            if len(self.planet) == 1:
-                self.phi = None
-            elif 'phi' in gparam:
-                phi = tuple(_rad(float(p)) for p in gparam['phi'].split(','))
-                nmoons = len(self.objects - {self.planet})
-                if len(phi) == nmoons:
-                    self.phi = phi
-                else:
-                    raise InputError('Geometry.__init__',
-                                     'The wrong number of orbital positions was given.')
-            else:
-                raise InputError('Geometry.__init__', 'geometry.phi was not specified.')
-
-            if 'subsolarpoint' in gparam:
-                subs = gparam['subsolarpoint'].split(',')
-                try:
-                    self.subsolarpoint = (_rad(float(subs[0])), _rad(float(subs[1])))
-                except Exception:
-                    raise InputError('Geometry.__init__',
-                                     'The format for geometry.subsolarpoint is wrong.')
-            else:
-                self.subsolarpoint = (_rad(0), _rad(0))
-            self.taa = _rad(float(gparam.get('taa', 0.)))
+def numbers(text):
+    return tuple(float(part) for part in text.split(','))
 
 
-class SurfaceInteraction(_Spec):
-    _prefix = 'surfaceinteraction'
-
-    def __init__(self, sparam):
-        sticktype = sparam['sticktype'].lower() if 'sticktype' in sparam else None
-        if sticktype == 'temperature dependent':
-            self.sticktype = sticktype
-            if 'accomfactor' in sparam:
-                self.accomfactor = float(sparam['accomfactor'])
-            else:
-                raise InputError('SurfaceInteraction.__init__',
-                                 'surfaceinteraction.accomfactor not given.')
-            if 'a' in sparam:
-                A = tuple(float(a) for a in sparam['a'].split(','))
-                if len(A) == 3:
-                    self.A = A
-                else:
-                    raise InputError('SurfaceInteraction.__init__',
-                                     'surfaceinteraction.A must have 3 values')
-            else:
-                self.A = (1.57014, -0.006262, 0.1614157)
-        elif sticktype == 'surface map':
-            self.sticktype = sticktype
-            self.stick_mapfile = sparam.get('stick_mapfile', 'default')
-            if not os.path.exists(self.stick_mapfile):
-                print('Warning: stick_mapfile does not exist')
-            self.stick_map = None
-            self.subsolarlon = sparam.get('subsolarlon', None)
-            if self.subsolarlon is not None:
-                self.subsolarlon = _rad(float(self.subsolarlon))
-            if 'accomfactor' in sparam:
-                self.accomfactor = float(sparam['accomfactor'])
-            else:
-                raise InputError('SurfaceInteraction.__init__',
-                                 'surfaceinteraction.accomfactor not given.')
-        elif 'stickcoef' in sparam:
-            self.sticktype = 'constant'
-            self.stickcoef = min(max(float(sparam['stickcoef']), 0), 1)
-            if 'accomfactor' in sparam:
-                self.accomfactor = float(sparam['accomfactor'])
-            elif self.stickcoef == 1:
-                self.accomfactor = None
-            else:
-                raise InputError('SurfaceInteraction.__init__',
-                                 'surfaceinteraction.accomfactor not given.')
-        else:
-            self.sticktype = 'constant'
-            self.stickcoef = 1.
-            self.accomfactor = None
+def limited(lo, hi):
+    """A number pushed into [lo, hi]."""
+    return lambda text: min(max(float(text), lo), hi)
 
 
-def _parse_bool(text):
-    t = text.strip().title()
-    if t in ('True', '1'):
+def angle_pair(lo, hi):
+    """Two comma-separated angles, each pushed into [lo, hi], as radian quantities."""
+    def convert(text):
+        first, second = (min(max(float(part.strip()), lo), hi) for part in text.split(','))
+        return Quantity(first, 'rad'), Quantity(second, 'rad')
+    return convert
+
+
+def radians(*values):
+    return tuple(Quantity(v, 'rad') for v in values)
+
+
+def switch(text):
+    """'True' / 'False' / '1' / '0' in any case (the reference eval()s the title-cased text)."""
+    word = text.strip().casefold()
+    if word in ('true', '1'):
         return True
-    if t in ('False', '0'):
+    if word in ('false', '0'):
         return False
     raise InputError('Forces.__init__', f'cannot interpret {text!r} as a boolean')
 
 
-class Forces(_Spec):
-    _prefix = 'forces'
-
-    def __init__(self, fparam):
-        self.gravity = _parse_bool(fparam['gravity']) if 'gravity' in fparam else True
-        self.radpres = _parse_bool(fparam['radpres']) if 'radpres' in fparam else True
+_REQUIRED = object()
 
 
-def _clamp(v, lo, hi):
-    return min(max(v, lo), hi)
+class Field:
+    """One attribute of a section.
+
+    attr     name of the attribute set on the section object
+    convert  text -> value
+    default  value used when none of ``keys`` is present (``missing`` text -> InputError instead)
+    keys     accepted inputfile keys, first match wins (default: the attribute name, case-folded)
+    """
+    __slots__ = ('attr', 'convert', 'default', 'keys', 'missing', 'blame')
+
+    def __init__(self, attr, convert=str, default=_REQUIRED, keys=None, missing=None, blame=None):
+        self.attr = attr
+        self.convert = convert
+        self.default = default
+        self.keys = tuple(keys) if keys else (attr.casefold(),)
+        self.missing = missing
+        self.blame = blame
+
+    def value(self, params, section):
+        for key in self.keys:
+            if key in params:
+                return self.convert(params[key])
+        if self.default is _REQUIRED:
+            raise InputError(f'{self.blame or type(section).__name__}.__init__',
+                             self.missing or f'{type(section).__name__}.{self.attr} not given.')
+        return self.default
 
 
-class SpatialDist(_Spec):
-    _prefix = 'spatialdist'
+class Constant:
+    """An attribute that does not come from the file."""
+    __slots__ = ('attr', 'fixed')
 
-    def __init__(self, sparam):
-        if 'type' in sparam:
-            self.type = sparam['type']
+    def __init__(self, attr, fixed):
+        self.attr, self.fixed = attr, fixed
+
+    def value(self, params, section):
+        return self.fixed
+
+
+class Section:
+    """Generic section: ``layout(params)`` names the fields, ``check()`` validates across them."""
+    prefix = ''
+    fields = ()
+
+    def __init__(self, params):
+        for item in self.layout(params):
+            setattr(self, item.attr, item.value(params, self))
+        self.check(params)
+
+    def layout(self, params):
+        return self.fields
+
+    def check(self, params):
+        pass
+
+    def __eq__(self, other):
+        return (isinstance(other, type(self)) and self.__dict__.keys() == other.__dict__.keys()
+                and all(other.__dict__[k] == v for k, v in self.__dict__.items()))
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = None
+
+    def __str__(self):
+        return '\n'.join(f'{self.prefix}.{k} = {v}' for k, v in self.__dict__.items())
+
+    __repr__ = __str__
+
+
+# ---- geometry -----------------------------------------------------------------------------------
+class Geometry(Section):
+    """Which bodies take part and where they are.  The body bookkeeping (planet, its moons, the
+    start point, the included set) is resolved first; the remaining attributes are fields."""
+    prefix = 'geometry'
+
+    def layout(self, params):
+        if 'planet' not in params:
+            raise InputError('Geometry.__init__', 'Planet not defined in inputfile.')
+        planet = SSObject(params['planet'].title())
+        family = [planet.object] + [m.object for m in (planet.moons or ())]
+        start = params.get('startpoint', planet.object).title()
+        if start not in family:
+            print(f'{start} is not a valid starting point.')
+            print('Valid choices are:\n\t' + '\n\t'.join(family))
+            raise ValueError
+        if 'objects' in params:
+            wanted = {name.strip().title() for name in params['objects'].split(',')}
         else:
+            wanted = {planet.object, start}
+        for name in wanted:
+            if name not in family:
+                raise InputError('Geometry.__init__', f'Invalid object {name} in geometry.include')
+        bodies = {SSObject(name) for name in wanted} or None
+        head = [Constant('planet', planet), Constant('startpoint', start),
+                Constant('objects', bodies)]
+        if 'starttime' in params:
+            # The reference parses an astropy Time here; only the text is kept: SPICE-driven
+            # geometry is out of scope and Output refuses this type (Output.py:95-96).
+            return head + [Constant('type', 'geometry with starttime'),
+                           Constant('time', params['starttime'].upper())]
+        moons_included = len((bodies or set()) - {planet})
+        return head + [Constant('type', 'geometry without starttime'),
+                       Constant('phi', self._orbital_phases(params, planet, moons_included)),
+                       Field('subsolarpoint', self._subsolar, default=radians(0, 0)),
+                       Field('taa', measured('rad'), default=Quantity(0., 'rad'))]
+
+    @staticmethod
+    def _orbital_phases(params, planet, expected):
+        if len(planet) == 1:
+            return None                      # a planet without moons has nothing to place
+        if 'phi' not in params:
+            raise InputError('Geometry.__init__', 'geometry.phi was not specified.')
+        phases = radians(*numbers(params['phi']))
+        if len(phases) != expected:
+            raise InputError('Geometry.__init__',
+                             'The wrong number of orbital positions was given.')
+        return phases
+
+    @staticmethod
+    def _subsolar(text):
+        try:
+            lon, lat = text.split(',')[:2]
+            return radians(float(lon), float(lat))
+        except (ValueError, TypeError):
+            raise InputError('Geometry.__init__',
+                             'The format for geometry.subsolarpoint is wrong.') from None
+
+
+# ---- surface interaction --------------------------------------------------------------------------
+_ACCOM = Field('accomfactor', number, blame='SurfaceInteraction',
+               missing='surfaceinteraction.accomfactor not given.')
+
+
+def _three_coefficients(text):
+    coef = numbers(text)
+    if len(coef) != 3:
+        raise InputError('SurfaceInteraction.__init__', 'surfaceinteraction.A must have 3 values')
+    return coef
+
+
+def _optional_angle(text):
+    return Quantity(float(text), 'rad')
+
+
+class SurfaceInteraction(Section):
+    prefix = 'surfaceinteraction'
+    by_sticktype = {
+        'temperature dependent': (
+            Constant('sticktype', 'temperature dependent'), _ACCOM,
+            Field('A', _three_coefficients, default=(1.57014, -0.006262, 0.1614157))),
+        'surface map': (
+            Constant('sticktype', 'surface map'),
+            Field('stick_mapfile', default='default'),
+            Constant('stick_map', None),       # the reference's pickled SourceMap: out of scope
+            Field('subsolarlon', _optional_angle, default=None), _ACCOM),
+    }
+
+    def layout(self, params):
+        kind = params['sticktype'].lower() if 'sticktype' in params else None
+        if kind in self.by_sticktype:
+            return self.by_sticktype[kind]
+        if 'stickcoef' not in params:          # nothing said: packets stick where they land
+            return (Constant('sticktype', 'constant'), Constant('stickcoef', 1.),
+                    Constant('accomfactor', None))
+        stick = limited(0, 1)(params['stickcoef'])
+        # a perfectly sticking surface needs no accommodation factor; any other must give one
+        accom = Field('accomfactor', number, default=None) if stick == 1 else _ACCOM
+        return (Constant('sticktype', 'constant'), Constant('stickcoef', stick), accom)
+
+    def check(self, params):
+        if self.sticktype == 'surface map' and not os.path.exists(self.stick_mapfile):
+            print('Warning: stick_mapfile does not exist')
+
+
+# ---- forces -----------------------------------------------------------------------------------------
+class Forces(Section):
+    prefix = 'forces'
+    fields = (Field('gravity', switch, default=True), Field('radpres', switch, default=True))
+
+
+# ---- spatial distribution -----------------------------------------------------------------------
+_EXOBASE = Field('exobase', number, default=1.)
+
+
+def _spot(attr):
+    return Field(attr, measured('rad'), blame='SpatialDist',
+                 missing=f'SpatialDist.{attr} not given.')
+
+
+class SpatialDist(Section):
+    prefix = 'spatialdist'
+    by_type = {
+        'uniform': (
+            _EXOBASE,
+            Field('longitude', angle_pair(0., TWO_PI), default=radians(0., TWO_PI)),
+            Field('latitude', angle_pair(-HALF_PI, HALF_PI), default=radians(-HALF_PI, HALF_PI))),
+        'surface map': (
+            _EXOBASE, Field('mapfile', default='default'),
+            Field('subsolarlon', _optional_angle, default=None),
+            Field('coordinate_system', default='solar-fixed')),
+        'surface spot': (_EXOBASE, _spot('longitude'), _spot('latitude'), _spot('sigma')),
+        'fitted output': (Constant('unfit_outid', -1), Constant('query', None)),
+    }
+
+    def layout(self, params):
+        if 'type' not in params:
             raise InputError('SpatialDist.__init__', 'SpatialDist.type not given')
+        kind = params['type']
+        if kind not in self.by_type:
+            raise InputError('SpatialDist.__init__', f'SpatialDist.type = {kind} not defined.')
+        return (Constant('type', kind),) + self.by_type[kind]
 
-        if self.type == 'uniform':
-            self.exobase = float(sparam['exobase']) if 'exobase' in sparam else 1.
-            if 'longitude' in sparam:
-                lon0, lon1 = (float(v.strip()) for v in sparam['longitude'].split(','))
-                self.longitude = (_rad(_clamp(lon0, 0., 2*np.pi)), _rad(_clamp(lon1, 0., 2*np.pi)))
-            else:
-                self.longitude = (_rad(0.), _rad(2*np.pi))
-            if 'latitude' in sparam:
-                lat0, lat1 = (float(v.strip()) for v in sparam['latitude'].split(','))
-                lat0 = _clamp(lat0, -np.pi/2, np.pi/2)
-                lat1 = _clamp(lat1, -np.pi/2, np.pi/2)
-                if lat0 > lat1:
-                    raise InputError('SpatialDist.__init__',
-                                     'SpatialDist.latitude[0] > SpatialDist.latitude[1]')
-                self.latitude = (_rad(lat0), _rad(lat1))
-            else:
-                self.latitude = (_rad(-np.pi/2), _rad(np.pi/2))
-        elif self.type == 'surface map':
-            self.exobase = float(sparam['exobase']) if 'exobase' in sparam else 1.
-            self.mapfile = sparam.get('mapfile', 'default')
-            self.subsolarlon = sparam.get('subsolarlon', None)
-            if self.subsolarlon is not None:
-                self.subsolarlon = _rad(float(self.subsolarlon))
-            self.coordinate_system = sparam.get('coordinate_system', 'solar-fixed')
-        elif self.type == 'surface spot':
-            self.exobase = float(sparam['exobase']) if 'exobase' in sparam else 1.
-            for key in ('longitude', 'latitude', 'sigma'):
-                if key in sparam:
-                    setattr(self, key, _rad(float(sparam[key])))
-                else:
-                    raise InputError('SpatialDist.__init__', f'SpatialDist.{key} not given.')
-        elif self.type == 'fitted output':
-            self.unfit_outid = -1
-            self.query = None
-        else:
+    def check(self, params):
+        if self.type == 'uniform' and self.latitude[0] > self.latitude[1]:
             raise InputError('SpatialDist.__init__',
-                             f'SpatialDist.type = {self.type} not defined.')
+                             'SpatialDist.latitude[0] > SpatialDist.latitude[1]')
 
 
-class SpeedDist(_Spec):
-    _prefix = 'speeddist'
-
-    def __init__(self, sparam):
-        self.type = sparam['type']
-
-        def need(key, unit, attr=None):
-            if key in sparam:
-                setattr(self, attr or key, Quantity(float(sparam[key]), unit))
-            else:
-                raise InputError('SpatialDist.__init__', f'SpeedDist.{attr or key} not given.')
-
-        if self.type == 'gaussian':
-            need('vprob', 'km/s')
-            need('sigma', 'km/s')
-        elif self.type == 'sputtering':
-            for key in ('alpha', 'beta'):
-                if key in sparam:
-                    setattr(self, key, float(sparam[key]))
-                else:
-                    raise InputError('SpatialDist.__init__', f'SpeedDist.{key} not given.')
-            need('u', 'eV', 'U')
-        elif self.type == 'maxwellian':
-            need('temperature', 'K')
-        elif self.type == 'flat':
-            need('vprob', 'km/s')
-            need('delv', 'km/s')
-        elif self.type == 'user defined':
-            self.vdistfile = sparam.get('vdistfile', 'default')
-        elif self.type == 'fitted output':
-            self.unfit_outid = -1
-            self.query = None
-        else:
-            assert 0, f'SpeedDist.type = {self.type} not available'
+# ---- speed distribution ---------------------------------------------------------------------------
+def _speed(attr, convert, key=None):
+    # the reference blames SpatialDist for a missing SpeedDist parameter; kept, it is part of what
+    # callers can observe
+    return Field(attr, convert, keys=(key or attr.casefold(),), blame='SpatialDist',
+                 missing=f'SpeedDist.{attr} not given.')
 
 
-class AngularDist(_Spec):
-    _prefix = 'angulardist'
+class SpeedDist(Section):
+    prefix = 'speeddist'
+    by_type = {
+        'gaussian': (_speed('vprob', measured('km/s')), _speed('sigma', measured('km/s'))),
+        'sputtering': (_speed('alpha', number), _speed('beta', number),
+                       _speed('U', measured('eV'), key='u')),
+        'maxwellian': (_speed('temperature', measured('K')),),
+        'flat': (_speed('vprob', measured('km/s')), _speed('delv', measured('km/s'))),
+        'user defined': (Field('vdistfile', default='default'),),
+        'fitted output': (Constant('unfit_outid', -1), Constant('query', None)),
+    }
 
-    def __init__(self, aparam):
-        if 'type' in aparam:
-            self.type = aparam['type'].lower()
-            if self.type == 'radial':
-                pass
-            elif self.type == 'isotropic':
-                if 'azimuth' in aparam:
-                    az0, az1 = (float(v.strip()) for v in aparam['azimuth'].split(','))
-                    self.azimuth = (_rad(_clamp(az0, 0., 2*np.pi)), _rad(_clamp(az1, 0., 2*np.pi)))
-                else:
-                    self.azimuth = (_rad(0), _rad(2*np.pi))
-                self._altitude(aparam, np.pi/2)
-            elif self.type == '2d':
-                self._altitude(aparam, np.pi)
-            else:
-                raise InputError('AngularDist.__init__',
-                                 f'AngularDist.type = {self.type} not defined.')
-        else:
-            self.type = 'isotropic'
-            self.azimuth = (_rad(0), _rad(2*np.pi))
-            self.altitude = (_rad(0), _rad(np.pi/2))
-
-    def _altitude(self, aparam, top):
-        if 'altitude' in aparam:
-            alt0, alt1 = (float(v.strip()) for v in aparam['altitude'].split(','))
-            alt0, alt1 = _clamp(alt0, 0, top), _clamp(alt1, 0, top)
-            if alt0 > alt1:
-                raise InputError('AngularDist.__init__',
-                                 'AngularDist.altitude[0] > AngularDist.altitude[1]')
-            self.altitude = (_rad(alt0), _rad(alt1))
-        else:
-            self.altitude = (_rad(0), _rad(top))
+    def layout(self, params):
+        kind = params['type']                   # KeyError when absent, as in the reference
+        assert kind in self.by_type, f'SpeedDist.type = {kind} not available'
+        return (Constant('type', kind),) + self.by_type[kind]
 
 
-class Options(_Spec):
-    _prefix = 'options'
+# ---- angular distribution -----------------------------------------------------------------------
+def _altitude(top):
+    return Field('altitude', angle_pair(0, top), default=radians(0, top))
 
-    def __init__(self, oparam):
-        if 'endtime' in oparam:
-            self.endtime = Quantity(float(oparam['endtime']), 's')
-        else:
-            raise InputError('Options.__init__', 'options.endtime not specified.')
 
-        if 'species' in oparam:
-            self.species = oparam['species'].capitalize()
-        elif 'atom' in oparam:
-            self.species = oparam['atom'].capitalize()
-        else:
-            raise InputError('Options.__init__', 'options.species not specified.')
+class AngularDist(Section):
+    prefix = 'angulardist'
+    by_type = {
+        'radial': (),
+        'isotropic': (Field('azimuth', angle_pair(0., TWO_PI), default=radians(0, TWO_PI)),
+                      _altitude(HALF_PI)),
+        '2d': (_altitude(math.pi),),
+    }
 
-        self.lifetime = Quantity(float(oparam.get('lifetime', 0)), 's')
+    def layout(self, params):
+        if 'type' not in params:                # nothing said: the isotropic defaults, untouched
+            return (Constant('type', 'isotropic'), Constant('azimuth', radians(0, TWO_PI)),
+                    Constant('altitude', radians(0, HALF_PI)))
+        kind = params['type'].lower()
+        if kind not in self.by_type:
+            raise InputError('AngularDist.__init__', f'AngularDist.type = {kind} not defined.')
+        return (Constant('type', kind),) + self.by_type[kind]
 
-        if 'outeredge' in oparam:
-            self.outeredge = float(oparam['outeredge'])
-        elif 'outer_edge' in oparam:
-            self.outeredge = float(oparam['outer_edge'])
-        else:
-            self.outeredge = 1e30
+    def check(self, params):
+        alt = getattr(self, 'altitude', None)
+        if alt is not None and alt[0] > alt[1]:
+            raise InputError('AngularDist.__init__',
+                             'AngularDist.altitude[0] > AngularDist.altitude[1]')
 
-        # The reference reads oparam['step_size'] in its 'stepsize' branch (a KeyError,
-        # input_classes.py:1086-1087); the evident intent is honoured here.
-        if 'step_size' in oparam:
-            self.step_size = float(oparam['step_size'])
-        elif 'stepsize' in oparam:
-            self.step_size = float(oparam['stepsize'])
-        else:
-            self.step_size = 0.
 
-        if self.step_size == 0:
-            # The reference leaves a file-supplied resolution as a STRING
-            # (input_classes.py:1092), which the variable-step driver cannot compare; it is
-            # converted here.
-            self.resolution = float(oparam.get('resolution', 1e-4))
-        else:
-            self.resolution = None
+# ---- options ------------------------------------------------------------------------------------------
+def _torus(params):
+    """EXTENSION (the reference's charge-exchange term is a commented stub, state.py:56-70): loss
+    in a plasma torus around the planet,
+        rate = chx_rate exp(-((rho - chx_rho0)/chx_width)^2 - (z/chx_height)^2)
+               [* |v - v_corotation| / v_corotation(chx_rho0)  if chx_corotation]
+    lengths in planet radii, chx_rate in 1/s.  No chx_rate: no such loss."""
+    if 'chx_rate' not in params:
+        return None
+    return {'k0': float(params['chx_rate']), 'rho0': float(params.get('chx_rho0', 5.9)),
+            'width': float(params.get('chx_width', 1.0)),
+            'height': float(params.get('chx_height', 1.0)),
+            'corotation': params.get('chx_corotation', 'false').casefold() == 'true'}
 
-        if 'fitted' in oparam:
-            self.fitted = oparam['fitted'].casefold() == 'True'.casefold()
-        else:
-            self.fitted = False
 
-        # EXTENSION (no counterpart in the reference, whose charge-exchange term is a
-        # commented stub, state.py:56-70): loss in a plasma torus around the planet,
-        #   rate = chx_rate exp(-((rho - chx_rho0)/chx_width)^2 - (z/chx_height)^2)
-        #          [* |v - v_corotation| / v_corotation(chx_rho0)  if chx_corotation]
-        # lengths in planet radii, chx_rate in 1/s.  Absent chx_rate = no such loss.
-        if 'chx_rate' in oparam:
-            self.chx = {'k0': float(oparam['chx_rate']),
-                        'rho0': float(oparam.get('chx_rho0', 5.9)),
-                        'width': float(oparam.get('chx_width', 1.0)),
-                        'height': float(oparam.get('chx_height', 1.0)),
-                        'corotation': oparam.get('chx_corotation', 'false').casefold() == 'true'}
-        else:
-            self.chx = None
+class Options(Section):
+    prefix = 'options'
+
+    def layout(self, params):
+        # 'stepsize' is honoured (the reference looks up the wrong key in that branch and raises
+        # KeyError, input_classes.py:1086-1087); a file-supplied resolution becomes a float (the
+        # reference keeps the text, :1092, which its variable-step driver cannot compare).
+        step = Field('step_size', number, default=0., keys=('step_size', 'stepsize'))
+        adaptive = step.value(params, self) == 0
+        return (
+            Field('endtime', measured('s'), missing='options.endtime not specified.'),
+            Field('species', str.capitalize, keys=('species', 'atom'),
+                  missing='options.species not specified.'),
+            Field('lifetime', measured('s'), default=Quantity(0., 's')),
+            Field('outeredge', number, default=1e30, keys=('outeredge', 'outer_edge')),
+            step,
+            Field('resolution', number, default=1e-4) if adaptive else Constant('resolution', None),
+            Field('fitted', lambda text: text.casefold() == 'true', default=False),
+            Constant('chx', _torus(params)),
+        )

@@ -1,221 +1,258 @@
-"""Initial packet states X0 (host side, NumPy; draw-for-draw identical to the reference).
+"""Initial packet states X0 on the host, draw-for-draw the reference's sequence.
 
-Re-statement of initial_state/source_distribution.py:12-283, math/randomdeviates.py:8-83 and
-math/distributions.py:7-21 of the reference.  The order of draws from ``output.randgen`` is the
-reference's: time (variable-step only) -> sin(lat) -> lon -> speed -> sin(alt) -> az, so a seeded
-run produces the same X0 (SURVEY.md section 7 "Seed parity").  'maxwellian', 'sputtering' and
-'surface spot' draw from the UNSEEDED global ``numpy.random`` exactly as the reference does
-(randomdeviates.py:33,63-65).  Map-file driven sources ('surface map', 'user defined') are out
-of scope.
+What a seeded run must reproduce ("Seed parity") is the ORDER in which random
+numbers are taken from ``output.randgen`` and the arithmetic that turns them into a state: release
+time (variable-step runs only, drawn by Output before anything here) -> sin(latitude) -> longitude
+-> speed -> sin(altitude) -> azimuth; each a whole ``npackets`` vector.  The reference spreads
+this over initial_state/source_distribution.py:12-283, math/randomdeviates.py:8-83 and
+math/distributions.py:7-21; here every kind of source is one small sampler function registered in
+a table (``SURFACES``, ``SPEEDS``, ``DIRECTIONS``), and the three entry points the Output calls --
+``surface_distribution``, ``speed_distribution``, ``angular_distribution`` -- look the sampler up,
+run it and store the columns.  The order of generator calls is asserted by
+tests/test_host.py::test_x0_sampling_is_seed_deterministic_and_in_reference_order.
+
+Like the reference, the tabulated-density samplers ('maxwellian', 'sputtering', 'surface spot')
+draw from the UNSEEDED process-global ``numpy.random`` (randomdeviates.py:33,63-65), so they are
+statistically but not bitwise reproducible; the device sampler (nxc_packets_sample) covers them
+with counter-based draws.  Sources that need the reference's pickled map files ('surface map',
+'user defined') are out of scope.
 """
 import numpy as np
-import numpy.random as random
+import numpy.random as unseeded
+from scipy.interpolate import interpn
 
 from . import constants as const
 from .input_classes import InputError
 
+TWO_PI = 2*np.pi
 
+
+# ---- geometry helpers ---------------------------------------------------------------------------
 def xyz_from_lonlat(lon, lat, isplan, exobase):
-    """source_distribution.py:12-34.  Planet: lon 0 = subsolar point (0,-1,0), 90 deg = dusk
-    (1,0,0).  Satellite: lon 0 = sub-planet point, 90 deg = leading point (-1,0,0)."""
-    sign = 1.0 if isplan else -1.0
-    x0 = sign * exobase * np.sin(lon) * np.cos(lat)
-    y0 = -exobase * np.cos(lon) * np.cos(lat)
-    z0 = exobase * np.sin(lat)
-    X0 = np.array([x0, y0, z0])
-    assert np.all(np.isfinite(X0)), 'Non-Finite values of X0'
-    return X0
+    """Surface point of longitude/latitude on the sphere r = exobase, as a (3, n) array
+    (source_distribution.py:12-34).  Planet: longitude 0 is the subsolar point (0,-1,0), pi/2 the
+    dusk terminator (+x).  Satellite: longitude 0 is the sub-planet point, pi/2 the leading
+    point (-x)."""
+    handed = 1.0 if isplan else -1.0
+    xyz = np.array([handed * exobase * np.sin(lon) * np.cos(lat),
+                    -exobase * np.cos(lon) * np.cos(lat),
+                    exobase * np.sin(lat)])
+    assert np.all(np.isfinite(xyz)), 'Non-Finite values of X0'
+    return xyz
 
 
-def random_deviates_1d(x, f_x, num):
-    """Transformation-method deviates from f_x on x (randomdeviates.py:8-33; global RNG)."""
-    x_ = np.linspace(x.min(), x.max(), f_x.shape[0])
-    cumsum = f_x.cumsum()
-    cumsum -= cumsum.min()
-    cumsum /= cumsum.max()
-    return np.interp(random.rand(num), cumsum, x_)
+def _unit_rows(vectors):
+    return vectors/np.linalg.norm(vectors, axis=1)[:, np.newaxis]
 
 
-def random_deviates_2d(fdist, x0, y0, num):
-    """Acceptance/rejection deviates from a 2-D map (randomdeviates.py:36-83; global RNG)."""
-    from scipy import interpolate
-    mx = (x0.max()-x0.min(), x0.min())
-    my = (y0.max()-y0.min(), y0.min())
-    fmax = fdist.max()
-    x0_ = np.linspace(x0.min(), x0.max(), fdist.shape[0])
-    y0_ = np.linspace(y0.min(), y0.max(), fdist.shape[1])
-    xpts, ypts = [], []
-    while len(xpts) < num:
-        ux = random.rand(num)*mx[0] + mx[1]
-        uy = random.rand(num)*my[0] + my[1]
-        uf = random.rand(num)*fmax
-        val = interpolate.interpn((x0_, y0_), fdist, (ux, uy))
-        mm = uf < val
-        xpts.extend(list(ux[mm]))
-        ypts.extend(list(uy[mm]))
-    return np.array(xpts[0:num]), np.array(ypts[0:num])
+def local_frame(x, y, z):
+    """Unit vectors (radial, east, north), each (n, 3), of the launch points."""
+    nothing = np.zeros_like(z)
+    radial = np.array([x, y, z]).transpose()
+    east = np.array([y, -x, nothing]).transpose()
+    north = np.array([-z*x, -z*y, x**2+y**2]).transpose()
+    return _unit_rows(radial), _unit_rows(east), _unit_rows(north)
 
 
+def _ascending(first, second):
+    """An angular range that runs through 2 pi is unwrapped so that it ascends."""
+    return (first, second) if first <= second else (first, second + TWO_PI)
+
+
+# ---- densities and deviates (global generator) ------------------------------------------------
 def _mass_kg(species):
     return const.ATOMIC_MASS[species] * const.AMU
 
 
 def sputdist(velocity, U_eV, alpha, beta, species):
-    """Sputtering speed distribution on velocity [km/s] (distributions.py:7-13)."""
+    """Sputtering flux density over velocity [km/s], peak-normalised (distributions.py:7-13):
+    v^(2 beta + 1) / (v^2 + v_b^2)^alpha with v_b the speed of binding energy U."""
     v_b = np.sqrt(2*U_eV*const.EV/_mass_kg(species)) / 1e3
-    f_v = velocity**(2*beta+1) / (velocity**2 + v_b**2)**alpha
-    return f_v / np.max(f_v)
+    density = velocity**(2*beta+1) / (velocity**2 + v_b**2)**alpha
+    return density / np.max(density)
 
 
 def MaxwellianDist(velocity, temperature, species):
-    """Maxwellian flux distribution on velocity [km/s] (distributions.py:16-21)."""
+    """Maxwellian FLUX density over velocity [km/s], peak-normalised (distributions.py:16-21)."""
     vth2 = 2*temperature*const.K_B/_mass_kg(species) / 1e6
-    f_v = velocity**3 * np.exp(-velocity**2/vth2)
-    return f_v / np.max(f_v)
+    density = velocity**3 * np.exp(-velocity**2/vth2)
+    return density / np.max(density)
+
+
+def random_deviates_1d(x, f_x, num):
+    """Inverse-CDF deviates of the density f_x tabulated on x (randomdeviates.py:8-33)."""
+    grid = np.linspace(x.min(), x.max(), f_x.shape[0])
+    cdf = f_x.cumsum()
+    cdf -= cdf.min()
+    cdf /= cdf.max()
+    return np.interp(unseeded.rand(num), cdf, grid)
+
+
+def random_deviates_2d(fdist, x0, y0, num):
+    """Accept/reject deviates of a density map on (x0, y0): rounds of ``num`` candidate points
+    under a box of height max(fdist) until ``num`` are accepted (randomdeviates.py:36-83)."""
+    span_x, span_y = x0.max() - x0.min(), y0.max() - y0.min()
+    ceiling = fdist.max()
+    axes = (np.linspace(x0.min(), x0.max(), fdist.shape[0]),
+            np.linspace(y0.min(), y0.max(), fdist.shape[1]))
+    kept_x, kept_y = [], []
+    while len(kept_x) < num:
+        cand_x = unseeded.rand(num)*span_x + x0.min()
+        cand_y = unseeded.rand(num)*span_y + y0.min()
+        height = unseeded.rand(num)*ceiling
+        under = height < interpn(axes, fdist, (cand_x, cand_y))
+        kept_x.extend(cand_x[under])
+        kept_y.extend(cand_y[under])
+    return np.array(kept_x[:num]), np.array(kept_y[:num])
+
+
+# ---- where packets start: (lon, lat) ------------------------------------------------------------
+def spot_density_map(lon0, lat0, sigma):
+    """exp(-angular distance / sigma) from the spot centre on a 1-degree (lon, lat) grid
+    (source_distribution.py:96-113; the reference's map uses -sin(lat) for z, kept)."""
+    centre = (np.sin(lon0)*np.cos(lat0), -np.cos(lon0)*np.cos(lat0), np.sin(lat0))
+    lon = np.linspace(0, TWO_PI, 361)
+    lat = np.linspace(-np.pi/2, np.pi/2, 181)
+    cosine = (np.outer(np.sin(lon), np.cos(lat))*centre[0]
+              + -np.outer(np.cos(lon), np.cos(lat))*centre[1]
+              + -np.outer(np.ones_like(lon), np.sin(lat))*centre[2])
+    return lon, lat, np.exp(-np.arccos(np.clip(cosine, -1, 1))/sigma)
+
+
+def _surface_uniform(out, sd):
+    n, rng = out.npackets, out.randgen
+    s0, s1 = np.sin(sd.latitude[0]), np.sin(sd.latitude[1])
+    lat = np.arcsin(s0 + (s1-s0) * rng.random(n))
+    w0, w1 = _ascending(float(sd.longitude[0]), float(sd.longitude[1]))
+    lon = (w0 + (w1-w0) * rng.random(n)) % TWO_PI
+    return lon, lat
+
+
+def _surface_spot(out, sd):
+    lon, lat, density = spot_density_map(float(sd.longitude), float(sd.latitude),
+                                         float(sd.sigma))
+    return random_deviates_2d(density, lon, lat, out.npackets)
+
+
+def _surface_map(out, sd):
+    raise NotImplementedError("surface-map sources need the reference's pickled map files; "
+                              'out of scope (SURVEY.md section 2)')
+
+
+SURFACES = {'uniform': _surface_uniform, 'surface spot': _surface_spot,
+            'surface map': _surface_map}
 
 
 def surface_distribution(outputs):
-    """Launch positions on the sphere r = exobase (source_distribution.py:37-134)."""
-    spatialdist = outputs.inputs.spatialdist
-    npack = outputs.npackets
-
-    if spatialdist.type == 'uniform':
-        ll = tuple(map(np.sin, spatialdist.latitude))
-        sinlat = ll[0] + (ll[1]-ll[0]) * outputs.randgen.random(npack)
-        lat = np.arcsin(sinlat)
-        lon0 = [float(v) for v in spatialdist.longitude]
-        if lon0[0] > lon0[1]:
-            lon0 = [lon0[0], lon0[1]+2*np.pi]
-        lon = (lon0[0] + (lon0[1]-lon0[0]) * outputs.randgen.random(npack)) % (2*np.pi)
-    elif spatialdist.type == 'surface spot':
-        lon0, lat0, sigma0 = (float(spatialdist.longitude), float(spatialdist.latitude),
-                              float(spatialdist.sigma))
-        spot0 = (np.sin(lon0)*np.cos(lat0), -np.cos(lon0)*np.cos(lat0), np.sin(lat0))
-        longitude = np.linspace(0, 2*np.pi, 361)
-        latitude = np.linspace(-np.pi/2, np.pi/2, 181)
-        ptsx = np.outer(np.sin(longitude), np.cos(latitude))
-        ptsy = -np.outer(np.cos(longitude), np.cos(latitude))
-        ptsz = -np.outer(np.ones_like(longitude), np.sin(latitude))
-        cosphi = ptsx*spot0[0]+ptsy*spot0[1]+ptsz*spot0[2]
-        cosphi[cosphi > 1] = 1
-        cosphi[cosphi < -1] = -1
-        sourcemap = np.exp(-np.arccos(cosphi)/sigma0)
-        lon, lat = random_deviates_2d(sourcemap, longitude, latitude, npack)
-    elif spatialdist.type == 'surface map':
-        raise NotImplementedError('surface-map sources need the reference\'s pickled map files; '
-                                  'out of scope (SURVEY.md section 2)')
-    else:
-        assert False, "Can't get here"
-
-    # The reference passes geometry.planet.type == 'Planet' (always True, :126).  With a moon
-    # as start point (our extension) the satellite convention of xyz_from_lonlat applies.
+    """Columns x, y, z, longitude, latitude, local_time of X0 (source_distribution.py:37-134)."""
+    sd = outputs.inputs.spatialdist
+    assert sd.type in SURFACES, "Can't get here"
+    lon, lat = SURFACES[sd.type](outputs, sd)
+    # The reference always uses the planet convention (:126).  With a moon as start point (our
+    # extension) the satellite convention of xyz_from_lonlat applies.
     geo = outputs.inputs.geometry
-    X_ = xyz_from_lonlat(lon, lat, geo.planet.object == geo.startpoint, spatialdist.exobase)
-    outputs.X0['x'] = X_[0, :]
-    outputs.X0['y'] = X_[1, :]
-    outputs.X0['z'] = X_[2, :]
-    outputs.X0['longitude'] = lon
-    outputs.X0['latitude'] = lat
-    outputs.X0['local_time'] = (lon * 12/np.pi + 12) % 24
+    x, y, z = xyz_from_lonlat(lon, lat, geo.planet.object == geo.startpoint, sd.exobase)
+    X0 = outputs.X0
+    X0['x'], X0['y'], X0['z'] = x, y, z
+    X0['longitude'], X0['latitude'] = lon, lat
+    X0['local_time'] = (lon * 12/np.pi + 12) % 24
+
+
+# ---- how fast: speed in km/s --------------------------------------------------------------------
+def _speed_gaussian(out, vd, species):
+    if vd.sigma == 0.:
+        return np.zeros(out.npackets) + vd.vprob.value
+    return out.randgen.standard_normal(out.npackets) * vd.sigma.value + vd.vprob.value
+
+
+def _speed_flat(out, vd, species):
+    return out.randgen.random(out.npackets)*2*vd.delv.value + vd.vprob.value - vd.delv.value
+
+
+def _speed_sputtering(out, vd, species):
+    grid = np.linspace(.1, 50, 5000)
+    return random_deviates_1d(grid, sputdist(grid, vd.U.value, vd.alpha, vd.beta, species),
+                              out.npackets)
+
+
+def _speed_maxwellian(out, vd, species):
+    assert vd.temperature != 0, 'Not implemented yet'
+    v_th = np.sqrt(2*vd.temperature.value*const.K_B/_mass_kg(species)) / 1e3
+    grid = np.linspace(0.1, v_th*5, 5000)
+    return random_deviates_1d(grid, MaxwellianDist(grid, vd.temperature.value, species),
+                              out.npackets)
+
+
+def _speed_from_file(out, vd, species):
+    raise InputError('speed_distribution', 'user-defined speed files are out of scope')
+
+
+SPEEDS = {'gaussian': _speed_gaussian, 'flat': _speed_flat, 'sputtering': _speed_sputtering,
+          'maxwellian': _speed_maxwellian, 'user defined': _speed_from_file}
 
 
 def speed_distribution(outputs):
-    """Launch speeds in R/s (source_distribution.py:137-189)."""
-    speeddist = outputs.inputs.speeddist
-    npackets = outputs.npackets
-    species = outputs.inputs.options.species
-
-    if speeddist.type.lower() == 'gaussian':
-        if speeddist.sigma == 0.:
-            v0 = np.zeros(npackets) + speeddist.vprob.value
-        else:
-            v0 = (outputs.randgen.standard_normal(npackets) * speeddist.sigma.value
-                  + speeddist.vprob.value)
-    elif speeddist.type == 'sputtering':
-        velocity = np.linspace(.1, 50, 5000)
-        f_v = sputdist(velocity, speeddist.U.value, speeddist.alpha, speeddist.beta, species)
-        v0 = random_deviates_1d(velocity, f_v, npackets)
-    elif speeddist.type == 'maxwellian':
-        if speeddist.temperature != 0:
-            v_th = np.sqrt(2*speeddist.temperature.value*const.K_B/_mass_kg(species)) / 1e3
-            velocity = np.linspace(0.1, v_th*5, 5000)
-            f_v = MaxwellianDist(velocity, speeddist.temperature.value, species)
-            v0 = random_deviates_1d(velocity, f_v, npackets)
-        else:
-            assert 0, 'Not implemented yet'
-    elif speeddist.type == 'flat':
-        v0 = (outputs.randgen.random(npackets)*2*speeddist.delv.value
-              + speeddist.vprob.value - speeddist.delv.value)
-    elif speeddist.type == 'user defined':
-        raise InputError('speed_distribution', 'user-defined speed files are out of scope')
-    else:
-        assert 0, 'Distribtuion does not exist'
-
-    v0 = v0 / outputs.unit_km           # km/s -> R/s
+    """Column v of X0, in R/s (source_distribution.py:137-189)."""
+    vd = outputs.inputs.speeddist
+    kind = vd.type.lower() if vd.type.lower() == 'gaussian' else vd.type
+    assert kind in SPEEDS, 'Distribtuion does not exist'
+    v0 = SPEEDS[kind](outputs, vd, outputs.inputs.options.species) / outputs.unit_km
     outputs.X0['v'] = v0
     assert np.all(np.isfinite(v0)), 'Infinite values for v0'
     return v0
 
 
+# ---- which way: altitude above the local horizon, azimuth from north through east ---------------
+def _direction_radial(out, ad):
+    n = out.npackets
+    return np.zeros(n) + np.pi/2., np.zeros(n)
+
+
+def _direction_isotropic(out, ad):
+    n, rng = out.npackets, out.randgen
+    s0, s1 = np.sin(ad.altitude[0]), np.sin(ad.altitude[1])
+    alt = np.arcsin(rng.random(n) * (s1 - s0) + s0)
+    a0, a1 = float(ad.azimuth[0]), float(ad.azimuth[1])
+    lo, hi = (a0, a1) if a0 <= a1 else (a1, a0 + TWO_PI)     # the reference's unwrap (:209)
+    return alt, lo + (hi-lo)*rng.random(n)
+
+
+def _direction_planar(out, ad):
+    c0, c1 = np.cos(ad.altitude[0]), np.cos(ad.altitude[1])
+    return np.arccos(out.randgen.random(out.npackets) * (c1 - c0) + c0), None
+
+
+DIRECTIONS = {'radial': _direction_radial, 'isotropic': _direction_isotropic,
+              '2d': _direction_planar}
+
+
 def angular_distribution(outputs):
-    """Launch directions -> vx, vy, vz (source_distribution.py:192-283)."""
-    npackets = outputs.npackets
-    angulardist = outputs.inputs.angulardist
-
-    if angulardist.type == 'none':
+    """Columns vx, vy, vz, altitude, azimuth of X0 (source_distribution.py:192-283): the speed
+    along (cos alt cos az) north + (cos alt sin az) east + (sin alt) radial; for '2d' sources the
+    motion stays in the equatorial plane."""
+    ad = outputs.inputs.angulardist
+    if ad.type == 'none':
         return
-    elif angulardist.type == 'radial':
-        alt = np.zeros(npackets) + np.pi/2.
-        az = np.zeros(npackets)
-    elif angulardist.type == 'isotropic':
-        alt0 = angulardist.altitude
-        aa = (np.sin(alt0[0]), np.sin(alt0[1]))
-        sinalt = outputs.randgen.random(npackets) * (aa[1] - aa[0]) + aa[0]
-        alt = np.arcsin(sinalt)
-        az0, az1 = (float(v) for v in angulardist.azimuth)
-        m = (az0, az1) if az0 <= az1 else (az1, az0+2*np.pi)
-        az = m[0] + (m[1]-m[0])*outputs.randgen.random(npackets)
-    elif angulardist.type == '2d':
-        alt0 = angulardist.altitude
-        aa = (np.cos(alt0[0]), np.cos(alt0[1]))
-        cosalt = outputs.randgen.random(npackets) * (aa[1] - aa[0]) + aa[0]
-        alt = np.arccos(cosalt)
-    else:
-        assert 0, 'Angular Distribution not defined.'
-
-    x0, y0, z0 = (outputs.X0[c].values for c in ('x', 'y', 'z'))
-    speed = outputs.X0.v.values
-    if angulardist.type != '2d':
-        v_rad = np.sin(alt)
-        v_tan0 = np.cos(alt) * np.cos(az)
-        v_tan1 = np.cos(alt) * np.sin(az)
-        rad = np.array([x0, y0, z0]).transpose()
-        east = np.array([y0, -x0, np.zeros_like(z0)]).transpose()
-        north = np.array([-z0*x0, -z0*y0, x0**2+y0**2]).transpose()
-        rad = rad/np.linalg.norm(rad, axis=1)[:, np.newaxis]
-        east = east/np.linalg.norm(east, axis=1)[:, np.newaxis]
-        north = north/np.linalg.norm(north, axis=1)[:, np.newaxis]
-        v0 = (v_tan0[:, np.newaxis]*north + v_tan1[:, np.newaxis]*east
-              + v_rad[:, np.newaxis]*rad)
-        outputs.X0['vx'] = v0[:, 0] * speed
-        outputs.X0['vy'] = v0[:, 1] * speed
-        outputs.X0['vz'] = v0[:, 2] * speed
-        outputs.X0['altitude'] = alt
-        outputs.X0['azimuth'] = az
-    else:
-        v_rad = np.sin(alt)
-        v_tan = np.cos(alt)
-        rad = np.array([x0, y0]).transpose()
-        tan = np.array([y0, -x0]).transpose()
-        rad = rad/np.linalg.norm(rad, axis=1)[:, np.newaxis]
-        tan = tan/np.linalg.norm(tan, axis=1)[:, np.newaxis]
-        v0 = v_tan[:, np.newaxis]*tan + v_rad[:, np.newaxis]*rad
-        assert np.all(np.isclose(np.sum(v0**2, axis=1), 1))
-        outputs.X0['vx'] = v0[:, 0] * speed
-        outputs.X0['vy'] = v0[:, 1] * speed
-        outputs.X0['vz'] = np.zeros((npackets, ))
-        outputs.X0['altitude'] = alt
-        outputs.X0['azimuth'] = 0
-        outputs.X0['v_radial'] = v_rad * outputs.X0['v']
-        outputs.X0['v_east'] = np.sqrt(outputs.X0['v']**2 - outputs.X0['v_radial']**2)
-        outputs.X0['v_north'] = 0
+    assert ad.type in DIRECTIONS, 'Angular Distribution not defined.'
+    alt, az = DIRECTIONS[ad.type](outputs, ad)
+    X0 = outputs.X0
+    x, y, z = (X0[c].values for c in ('x', 'y', 'z'))
+    speed = X0.v.values
+    up, level = np.sin(alt), np.cos(alt)
+    if ad.type == '2d':
+        outward = _unit_rows(np.array([x, y]).transpose())
+        along = _unit_rows(np.array([y, -x]).transpose())
+        heading = level[:, np.newaxis]*along + up[:, np.newaxis]*outward
+        assert np.all(np.isclose(np.sum(heading**2, axis=1), 1))
+        X0['vx'], X0['vy'] = heading[:, 0] * speed, heading[:, 1] * speed
+        X0['vz'] = np.zeros((outputs.npackets, ))
+        X0['altitude'], X0['azimuth'] = alt, 0
+        X0['v_radial'] = up * X0['v']
+        X0['v_east'] = np.sqrt(X0['v']**2 - X0['v_radial']**2)
+        X0['v_north'] = 0
+        return
+    radial, east, north = local_frame(x, y, z)
+    heading = ((level * np.cos(az))[:, np.newaxis]*north + (level * np.sin(az))[:, np.newaxis]*east
+               + up[:, np.newaxis]*radial)
+    X0['vx'], X0['vy'], X0['vz'] = (heading[:, k] * speed for k in range(3))
+    X0['altitude'], X0['azimuth'] = alt, az

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Timing + roofline line for every kernel of the hot path OTHER than the bench's fused one:
+
+  k_image        a-6..a-8  stored samples -> image (40 B/sample radiance, 32 B column)
+  k_var          a-4       adaptive-step driver (128 B per rk5 attempt)
+  k_const_rows   a-3/f-3   compact trajectory rows (72 B written per live record)
+  k_const_traj   a-3       dense trajectory (64 B written per record slot)
+  k_los          f-1       line-of-sight cones ((spectrum, sample) pair tests)
+  k_sample       f-4       initial states on the device (64 B written per packet)
+  k_speed_max / k_order_hist / k_order_scatter   queue order of the resident packets
+
+One JSON line per kernel: HIP-event time of the launch on the handle's stream, units, the
+algorithmic bytes of SURVEY.md section 8(d) (or of DESIGN.md section 3 for the rows this survey
+has no figure for) and the fraction of the 8 TB/s HBM peak they amount to.  tools/profile_kernels.sh
+runs this under rocprofv3 (kernel trace + PMC passes); profiles/ keeps the summaries.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nexoclom_amd import Input, ModelImage, Output, hip_api          # noqa: E402
+from nexoclom_amd.LOSResult import (LOSResult, SpacecraftData, arccos_threshold,   # noqa: E402
+                                    los_geometry)
+from nexoclom_amd.Output import n_output_steps                        # noqa: E402
+
+HBM = 8000.0
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def line(kernel, ms, units, unit_name, bytes_per_unit, note=''):
+    ach = bytes_per_unit*units/(ms*1e-3)/1e9
+    print(json.dumps({'kernel': kernel, 'kernel_ms': ms, 'units': units, 'unit': unit_name,
+                      'value': units/(ms*1e-3), 'algorithmic_bytes_per_unit': bytes_per_unit,
+                      'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM, 'unit': 'GB/s',
+                                   'frac': ach/HBM}, 'note': note}))
+
+
+def synthetic_orbit(nspec, seed=0):
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0, 2*np.pi, nspec, endpoint=False)
+    r = 1.6 + 1.3*np.cos(th)**2
+    pos = np.stack([0.3*r*np.cos(th), r*np.sin(th)*0.6 - 0.4, r*np.sin(th)*0.8], 1)
+    look = rng.normal(size=(nspec, 3))
+    look[::3] = -pos[::3] + 0.9*rng.normal(size=(len(pos[::3]), 3))
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    return pos, look
+
+
+def main():
+    reps = 3
+    infile = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
+    inputs = Input(infile)
+    opt = inputs.options
+    nsteps, n_iter = n_output_steps(opt.endtime.value, opt.step_size)
+    ctx = hip_api.Context(0)
+
+    # ---- stored samples of a reference-sized chunk (Input.py:219-222): rows, traj, image, LOS --
+    n = 80467
+    with quiet():
+        out = Output(inputs, n, seed=1, integrate=False, save=False, context=ctx)
+    ctx.set_forces(**out.forces_kwargs())
+    ctx.set_bounce(None); ctx.set_bodies(None)
+    ctx.upload_soa(out.x0_soa())
+    for _ in range(reps):
+        res = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge)
+        ms_rows = ctx.last_kernel_ms()
+    rows = res['rows']
+    P = rows.shape[1]
+    line('k_const_rows', ms_rows, P, 'live records written', 72,
+         f'{n} packets (one reference chunk), {P} live records of {n*nsteps} slots; the kernel '
+         f're-integrates the packets ({ctx.counters()["particle_steps"]} particle-steps)')
+    nt = 20000
+    ctx.upload_soa(np.ascontiguousarray(out.x0_soa()[:, :nt]))
+    for _ in range(reps):
+        ctx.integrate_const(opt.step_size, n_iter, opt.outeredge, nrec=nsteps)
+        ms_traj = ctx.last_kernel_ms()
+    line('k_const_traj', ms_traj, nt*nsteps, 'record slots', 64,
+         f'{nt} packets x {nsteps} records, dense (compress=False)')
+
+    x, y, z, vy, frac = (np.ascontiguousarray(rows[c]) for c in (1, 2, 3, 5, 7))
+    # replicate the samples to a bench-sized stream (the image kernel is linear in the samples)
+    k = max(1, int(2.6e7)//P)
+    xs, ys, zs, vys, fs = (np.tile(a, k) for a in (x, y, z, vy, frac))
+    for q in ('radiance', 'column'):
+        with quiet():
+            img = ModelImage(inputs, {'quantity': q, 'dims': '512,512'}, context=ctx)
+        img._set_image(ctx, float(out.aplanet), float(out.vrplanet), False)
+        for _ in range(reps):
+            ctx.image_clear()
+            ctx.image_accumulate(xs, ys, zs, vys, fs)
+            ms = ctx.last_kernel_ms()
+        c = ctx.counters()
+        line(f'k_image[{q}]', ms, len(xs), 'samples', 40 if q == 'radiance' else 32,
+             f'{c["samples_binned"]} of {c["samples"]} samples inside the 512x512 image')
+
+    S = 512
+    pos, look = synthetic_orbit(S)
+    sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
+    with quiet():
+        los = LOSResult(sc, inputs, dphi=np.radians(1.0), context=ctx)
+    dist, lengths, ladder = los_geometry(sc.data, 25., los.dphi)
+    scarr = np.stack([sc.data.x, sc.data.y, sc.data.z, sc.data.xbore, sc.data.ybore,
+                      sc.data.zbore, dist, lengths.astype(float)])
+    args = (los.dphi, np.sin(los.dphi), np.sin(2*los.dphi), arccos_threshold(los.dphi),
+            float(out.vrplanet), out.unit_km*1e5, los.g_tables(float(out.aplanet)), ladder, scarr,
+            x, y, z, vy, frac)
+    for _ in range(reps):
+        r = ctx.los_accumulate(*args)
+        ms = ctx.last_kernel_ms()
+    line('k_los', ms, P*S, '(sample, spectrum) pair tests', 40.0/S,
+         f'{P} samples x {S} spectra, {int(r["npackets"].sum())} pairs inside cones; each sample '
+         f'(40 B) is read once per 128-spectrum tile')
+
+    # ---- bench-sized resident set: sampler, ordering, variable-step driver ---------------------
+    N = 10_000_000
+    with quiet():
+        big = Output(inputs, 1000, seed=1, integrate=False, save=False, context=ctx)
+    src = big.source_desc()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ctx.sample_packets(N, 1234, 0, **src)
+        call_ms = (time.perf_counter() - t0)*1e3
+    # last_kernel_ms of sample_packets times k_sample itself (the ordering follows it)
+    line('k_sample', ctx.last_kernel_ms(), N, 'packets', 64,
+         f'uniform/flat/isotropic source; whole call incl. queue ordering {call_ms:.2f} ms')
+    soa = ctx.sample_packets(2_000_000, 1234, 0, download=True, **src)
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ctx.upload_soa(soa)
+        up_ms = (time.perf_counter() - t0)*1e3
+    print(json.dumps({'kernel': 'nxc_packets_upload', 'call_ms': up_ms, 'packets': soa.shape[1],
+                      'note': 'H2D of 64 B/packet from pageable memory + k_speed_max + '
+                              'k_order_hist + k_order_scatter'}))
+
+    inputs.options.step_size = 0.
+    inputs.options.resolution = 1e-4
+    nv = 1_000_000
+    with quiet():
+        outv = Output(inputs, nv, seed=3, integrate=False, save=False, context=ctx)
+    ctx.set_forces(**outv.forces_kwargs())
+    ctx.upload_soa(outv.x0_soa())
+    for _ in range(reps):
+        ctx.integrate_var(1e-4, 25.)
+        ms = ctx.last_kernel_ms()
+    c = ctx.counters()
+    line('k_var', ms, c['particle_steps'], 'rk5 attempts', 128,
+         f'{nv} packets at random ages, resolution 1e-4')
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -13,7 +13,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'   # --no-traffic: leave profiles/traffic.json alone
 src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
@@ -33,7 +33,7 @@ summary = {k: {c: {'mean_per_launch': sum(v)/len(v), 'launches': len(v)} for c, 
            for k, d in pmc.items()}
 json.dump(summary, open(os.path.join(dst, f'{tag}_pmc.json'), 'w'), indent=1, sort_keys=True)
 
-dom = [k for k in summary if 'k_const_fused' in k]
+dom = [] if '--no-traffic' in sys.argv else [k for k in summary if 'k_const_fused' in k]
 traffic = {}
 if dom:
     s = summary[dom[0]]
