@@ -291,3 +291,30 @@ def test_host_samplers_for_other_sources():
     inp.speeddist.vprob, inp.speeddist.delv = Quantity(2., 'km/s'), Quantity(1., 'km/s')
     out = Output(inp, 20000, seed=1, integrate=False, save=False)
     assert abs(np.median(out.X0.longitude) - 1.0) < 0.05
+
+
+def test_tables_match_the_text_file_restatement():
+    """Row a-5 beyond one (planet, taa, species) point: RadPresConst / gValue ARRAYS for Na, Ca,
+    Mg at 0.3, 0.3514 and 1.5 au, PhotoRate for five species and planet_dist at five true
+    anomalies equal tests/golden/g7_tables.npz, which oracle/make_table_golden.py computed from
+    the reference's text data files with an independent restatement of its formulas."""
+    g = np.load(os.path.join(HERE, 'golden', 'g7_tables.npz'))
+    lines = {'Na': (3303, 5891, 5897), 'Ca': (2722, 4227, 4567), 'Mg': (2852,)}
+    for sp, waves in lines.items():
+        for k, a in enumerate(g['distances']):
+            rp = RadPresConst(sp, a)
+            assert np.array_equal(rp.velocity, g[f'{sp}_radpres_v'])
+            np.testing.assert_allclose(rp.accel, g[f'{sp}_radpres_a{k}'], rtol=4e-16, atol=0)
+            assert tuple(rp.wavelength) == waves
+            for w in waves:
+                gv = gValue(sp, w, a)
+                assert np.array_equal(gv.velocity, g[f'{sp}_{w}_v'])
+                assert np.array_equal(gv.g, g[f'{sp}_{w}_g{k}'])
+    for sp in ('Na', 'Ca', 'Mg', 'K', 'O'):
+        got = [PhotoRate(sp, a).rate.value for a in g['distances']]
+        assert np.array_equal(got, g[f'{sp}_photo'])
+    m = SSObject('Mercury')
+    for taa, (r, vr) in zip(g['mercury_taa'], g['mercury_r_vr']):
+        rr, vv = planet_dist(m, taa)
+        assert float(rr) == r and float(vv) == vr
+    assert m.GM.value/(m.radius.value*1e3)**3 == float(g['mercury_GM_R3'])

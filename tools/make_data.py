@@ -11,7 +11,15 @@ Sources (all plain text; no pickle is read):
   nexoclom/data/PlanetaryConstants.dat      ':'-separated table read as solarsystem/SSObject.py:102-114.
 
 Outputs are compact CSV files (data, not source): gvalues.csv, photorates.csv,
-planetary_constants.csv.
+planetary_constants.csv, every double written with 17 significant digits.
+
+Parsing note: the .dat files are read with pandas' DEFAULT float parser on purpose -- that is what
+the reference's own table builders use (initialize_atomicdata.py, SSObject.py:102-114), and it is
+not correctly rounded (about one value in five of the long g-value decimals lands 1 ulp off), so
+the doubles in the reference's tables are these, not the nearest doubles of the printed decimals;
+the cross-check against g-values_old.csv (the reference's dump of its own table) confirms it.  The
+CSVs written here are then read back by nexoclom_amd with a correctly rounded parser
+(atomicdata._lines, solarsystem._bodies), which returns exactly these doubles.
 """
 import glob
 import os
