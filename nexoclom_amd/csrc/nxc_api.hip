@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -104,6 +105,33 @@ struct PackedLut {
     std::vector<unsigned char> bytes;
 };
 
+// The device's cell computation (nxc_device.hpp: lut_cell), operation for operation: two roundings,
+// a saturating conversion, a clamp.
+int lut_cell_host(double x, double xbase, double inv_w, int ncell)
+{
+    const double s = (x - xbase) * inv_w;
+    long long c;
+    if (!(s >= 0.0)) c = 0;                       // negatives and NaN
+    else if (s >= 2147483647.0) c = 2147483647ll;
+    else c = (long long)s;
+    return (int)std::min<long long>(c, ncell + 1);
+}
+
+// Doubles as ordered unsigned integers (monotone for finite values and the infinities).
+unsigned long long ordered_key(double v)
+{
+    unsigned long long b;
+    std::memcpy(&b, &v, sizeof b);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+double from_ordered_key(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    std::memcpy(&v, &b, sizeof v);
+    return v;
+}
+
 int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, const char *what,
              int cells_per_node = 4)
 {
@@ -112,42 +140,58 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
     for (int64_t j = 0; j + 1 < n; j++)
         if (!(xp[j + 1] > xp[j]))
             return fail(NXC_ERR_ARG, std::string(what) + ": abscissae must be strictly ascending");
+    for (int64_t j = 0; j < n; j++)
+        if (!std::isfinite(xp[j]) || !std::isfinite(fp[j]))
+            return fail(NXC_ERR_ARG, std::string(what) + ": table values must be finite");
     int ncell = 64;
     while (ncell < cells_per_node * n && ncell < 16384) ncell <<= 1;
-    const size_t cell_bytes = ((size_t)(ncell + 1) * sizeof(unsigned short) + 31) & ~size_t(31);
-    // n table rows + one sentinel row in each of the two 16-byte-stride arrays
-    out.bytes.assign((size_t)(n + 1) * 32 + cell_bytes, 0);
-    double *rec = reinterpret_cast<double *>(out.bytes.data());
-    double *fs = rec + 2 * (n + 1);     // {fp, slope} pairs after the {xp, xp_next} pairs
+    const int64_t rows = n + 2;
+    const size_t cell_bytes = ((size_t)(ncell + 2) * sizeof(unsigned short) + 31) & ~size_t(31);
+    out.bytes.assign((size_t)rows * 32 + cell_bytes, 0);
+    double *rec = reinterpret_cast<double *>(out.bytes.data());     // {xp, xn} pairs
+    double *fs = rec + 2 * rows;                                    // {fp, slope} pairs
+    rec[0] = -std::numeric_limits<double>::max(); rec[1] = xp[0];   // row 0: below the table
+    fs[0] = fp[0]; fs[1] = 0.0;
     for (int64_t j = 0; j < n; j++) {
-        rec[2 * j + 0] = xp[j];
-        fs[2 * j + 0] = fp[j];
-        if (j + 1 < n) {      // np.interp's slope, the same IEEE quotient
-            fs[2 * j + 1] = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-            rec[2 * j + 1] = xp[j + 1];
-        } else {
-            fs[2 * j + 1] = 0.0;
-            rec[2 * j + 1] = HUGE_VAL;
-        }
-        if (!std::isfinite(fs[2 * j]) || !std::isfinite(fs[2 * j + 1]))
-            return fail(NXC_ERR_ARG, std::string(what) + ": table values must be finite");
+        const bool last = j + 1 == n;
+        rec[2 * (j + 1)] = xp[j];
+        rec[2 * (j + 1) + 1] = last ? HUGE_VAL : xp[j + 1];
+        fs[2 * (j + 1)] = fp[j];
+        // np.interp's slope, the same IEEE quotient
+        fs[2 * (j + 1) + 1] = last ? 0.0 : (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+        if (!std::isfinite(fs[2 * (j + 1) + 1]))
+            return fail(NXC_ERR_ARG, std::string(what) + ": table slopes must be finite");
     }
-    rec[2 * n + 0] = HUGE_VAL; rec[2 * n + 1] = HUGE_VAL;      // sentinel: never selected
-    fs[2 * n + 0] = fp[n - 1]; fs[2 * n + 1] = 0.0;
-    unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * (n + 1));
+    rec[2 * (n + 1)] = HUGE_VAL; rec[2 * (n + 1) + 1] = HUGE_VAL;   // sentinel: never selected
+    fs[2 * (n + 1)] = fp[n - 1]; fs[2 * (n + 1) + 1] = 0.0;
     const double x0 = xp[0], xl = xp[n - 1];
     const double inv_w = (double)ncell / (xl - x0);
-    for (int c = 0; c <= ncell; c++) {
-        const double edge = x0 + (double)c / inv_w;
-        int64_t j = std::upper_bound(xp, xp + n, edge) - xp - 1;   // largest j with xp[j] <= edge
-        cell[c] = (unsigned short)std::max<int64_t>(0, std::min<int64_t>(j, n - 1));
+    const double xbase = x0 - (xl - x0) / (double)ncell;
+    if (!std::isfinite(inv_w) || !std::isfinite(xbase) || !(xbase < x0))
+        return fail(NXC_ERR_ARG, std::string(what) + ": abscissa range cannot be indexed");
+    // cell[c] = the last row whose xp <= the smallest double that the device maps to cell c
+    // (bisection over the ordered doubles with the device's own arithmetic; cell 0 starts at
+    // -inf).  Row xp's: row 0 = -DBL_MAX, row j + 1 = xp[j].
+    unsigned short *cell = reinterpret_cast<unsigned short *>(rec + 4 * rows);
+    cell[0] = 0;
+    const unsigned long long k_lo = ordered_key(-std::numeric_limits<double>::max());
+    const unsigned long long k_hi = ordered_key(std::numeric_limits<double>::max());
+    for (int c = 1; c <= ncell + 1; c++) {
+        if (lut_cell_host(from_ordered_key(k_hi), xbase, inv_w, ncell) < c)
+            return fail(NXC_ERR_ARG, std::string(what) + ": cell index is not onto");
+        unsigned long long lo = k_lo, hi = k_hi;   // cell(lo) < c <= cell(hi)
+        while (hi - lo > 1) {
+            const unsigned long long mid = lo + (hi - lo) / 2;
+            if (lut_cell_host(from_ordered_key(mid), xbase, inv_w, ncell) >= c) hi = mid;
+            else lo = mid;
+        }
+        const double first = from_ordered_key(hi);
+        const int64_t j = std::upper_bound(xp, xp + n, first) - xp;  // nodes with xp <= first
+        cell[c] = (unsigned short)j;                                  // row j = node j - 1 (0: below)
     }
     out.desc.n = (int)n;
     out.desc.ncell = ncell;
-    out.desc.x0 = x0;
-    out.desc.xlast = xl;
-    out.desc.f_first = fp[0];
-    out.desc.f_last = fp[n - 1];
+    out.desc.xbase = xbase;
     out.desc.inv_w = inv_w;
     out.desc.offset_bytes = 0;
     out.desc.size_bytes = (int64_t)out.bytes.size();
@@ -255,7 +299,7 @@ int upload_blob(nxc_handle *h)
 {
     const size_t hb = NXC_HEADER_BYTES;
     const size_t ib = h->have_image ? h->image_part.size() : 0;
-    const size_t limit = 160 * 1024 - 32 - (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
+    const size_t limit = 160 * 1024 - 32 - (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES;
     size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
     while (h->have_forces && hb + fb + ib > limit && h->force_cells_per_node > 2) {
         h->force_cells_per_node /= 2;          // trade lookup hit rate for LDS space
@@ -356,7 +400,7 @@ int need_forces(nxc_handle *h)
 
 size_t persist_lds(size_t table_bytes)
 {
-    return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_STAGE_BYTES;
+    return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES;
 }
 
 // Per-step base phases of the moons, (cos, sin)(phi - omega (t0 - k h)), and the per-stage rotations
@@ -626,6 +670,8 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
 #endif
     G.nx = (int)d->nx;
     G.nz = (int)d->nz;
+    G.x_is_x = (d->M[0] == 1.0 && d->M[1] == 0.0 && d->M[2] == 0.0 && d->M[3] == 0.0 &&
+                d->M[6] == 0.0) ? 1 : 0;
     for (int l = 0; l < nl; l++) {
         PackedLut lut;
         int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
@@ -760,7 +806,7 @@ int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     HIPCHK(hipSetDevice(h->device));
     return guarded([&]() -> int {
-    // the device keeps {weight sum, count} interleaved in fp64 (see PixelAcc); split here
+    // the device keeps {weight sum, count} interleaved in fp64 (see image_add_pairs); split here
     std::vector<double> both(2 * h->npix);
     HIPCHK(hipMemcpyAsync(both.data(), h->d_image, 2 * h->npix * sizeof(double),
                           hipMemcpyDeviceToHost, h->stream));

@@ -12,29 +12,37 @@
 #include "nxc_math.hpp"
 
 // ---------------------------------------------------------------------------------------------
-// Lookup table with np.interp semantics (numpy compiled_base.c arr_interp): clamp to the end
-// values outside the table, else slope_j*(x - xp[j]) + fp[j] with
-// slope_j = (fp[j+1]-fp[j])/(xp[j+1]-xp[j]) (computed once on the host: same IEEE quotient; at a
-// node the product is +-0 and the sum is fp[j], np.interp's special case).
+// Lookup table with np.interp semantics (numpy compiled_base.c arr_interp): the end values outside
+// the table, else slope_j*(x - xp[j]) + fp[j] with slope_j = (fp[j+1]-fp[j])/(xp[j+1]-xp[j])
+// (computed once on the host: same IEEE quotient; at a node the product is +-0 and the sum is
+// fp[j], np.interp's special case).
 //
-// Global image of one table, staged verbatim into LDS (32-byte aligned):
-//   n pairs {xp[j], xp[j+1]}            (last: xp[n] = +inf)
-//   n pairs {fp[j], slope[j]}           (last: slope 0)
-//   then (ncell+1) uint16 cell->index entries, padded to a multiple of 32 bytes.
-// (Two 16-byte-stride arrays rather than one 32-byte record: a ds_read_b128 of random rows then
-// spreads over 16 bank quads instead of 8, which halves the LDS bank conflicts.)
-// cell[c] = the largest j with xp[j] <= left edge of uniform cell c.  A lookup is two dependent
-// LDS round trips: the cell entry, then records j and j+1 (four ds_read_b128); the record whose
-// [xp, xp_next) holds x is selected.  Cells are fine enough (ncell >= 4n) that this almost always
-// hits; otherwise a walk over the records finds the interval, so the result is exactly the j of
-// np.interp's bisection whatever the rounding of the cell computation.
+// Global image of one table of n nodes, staged verbatim into LDS (32-byte aligned).  Rows:
+//   row 0      "below the table"  {xp = -DBL_MAX, xn = xp[0]}   {fp = fp[0],   slope = 0}
+//   row j + 1  node j             {xp[j], xp[j+1] (+inf last)}  {fp[j], slope_j (0 for the last)}
+//   row n + 1  sentinel           {+inf, +inf}                  {fp[n-1], 0}
+// stored as two 16-byte-stride arrays ({xp, xn} pairs, then {fp, slope} pairs: a ds_read_b128 of
+// random rows then spreads over 16 bank quads instead of 8, which halves the LDS bank conflicts),
+// followed by (ncell + 2) uint16 cell entries, padded to a multiple of 32 bytes.
+//
+// A lookup needs no clamp and no lower-bound test: the cell of x is
+//   c = clamp(int((x - xbase) * inv_w), 0, ncell + 1),   xbase = xp[0] - one cell width,
+// so cell 0 collects everything below the table and cell ncell + 1 everything above it (the int
+// conversion saturates; the end rows have slope 0, so slope*(x - xp) + fp is the end value
+// there), and cell[c] = the last row whose xp is <= the SMALLEST double that maps to cell c -- the
+// host finds that double by bisection over this very arithmetic (nxc_api.hip: pack_lut), so
+// xp[row] <= x holds for every x of the cell whatever the rounding.  The lookup reads rows r and
+// r + 1 (four ds_read_b128; the +16 is an immediate offset) and takes the first whose xn is above
+// x; cells are fine enough (ncell >= 4n) that this almost always hits, otherwise a walk over the
+// rows finds the interval.  The result is exactly np.interp's for every finite or NaN x; an
+// INFINITE x gives NaN where np.interp gives the end value (0 * inf) -- callers treat a
+// non-finite state as an error anyway.
 // ---------------------------------------------------------------------------------------------
 struct LutDesc {          // host-filled, passed by value in kernel arguments
-    int n;                // table length
-    int ncell;            // number of uniform cells over [x0, xlast]
-    double x0, xlast;     // xp[0], xp[n-1]
-    double f_first, f_last;   // fp[0], fp[n-1] (np.interp's left/right values)
-    double inv_w;         // ncell / (xlast - x0)
+    int n;                // number of nodes (rows = n + 2)
+    int ncell;            // uniform cells over [xp[0], xp[n-1]] (cell entries = ncell + 2)
+    double xbase;         // xp[0] - (xp[n-1] - xp[0]) / ncell
+    double inv_w;         // ncell / (xp[n-1] - xp[0])
     int64_t offset_bytes; // byte offset of this table inside the packed table blob (32-aligned)
     int64_t size_bytes;   // bytes of this table in the blob (multiple of 32)
 };
@@ -52,71 +60,59 @@ NXC_DEV int lds_u16(int byte_off)
     return *reinterpret_cast<const unsigned short *>(nxc_lds + byte_off);
 }
 
-struct LutRec { double xp, fp, sl, xn; };
-
 NXC_DEV double2 lds_f64x2(int byte_off)
 {
     return *reinterpret_cast<const double2 *>(nxc_lds + byte_off);
 }
 
 struct LutView {          // byte offsets into the LDS block
-    int rec, fs, cell;    // {xp, xp_next} pairs, {fp, slope} pairs, cell index
-    int n, ncell;
-    double x0, xlast, f_first, f_last, inv_w;
+    int rec, fs, cell;    // {xp, xn} pairs, {fp, slope} pairs, cell index
+    int top;              // ncell + 1: the last cell entry
+    int last;             // n + 1: the sentinel row
+    double xbase, inv_w;
 };
 
 NXC_DEV LutView lut_view(const LutDesc &d)
 {
     LutView v;
     v.rec = (int)d.offset_bytes;
-    v.fs = v.rec + 16 * (d.n + 1);        // each array carries one sentinel row after the table
-    v.cell = v.rec + 32 * (d.n + 1);
-    v.n = d.n; v.ncell = d.ncell; v.x0 = d.x0; v.xlast = d.xlast;
-    v.f_first = d.f_first; v.f_last = d.f_last; v.inv_w = d.inv_w;
+    v.fs = v.rec + 16 * (d.n + 2);
+    v.cell = v.rec + 32 * (d.n + 2);
+    v.top = d.ncell + 1;
+    v.last = d.n + 1;
+    v.xbase = d.xbase; v.inv_w = d.inv_w;
     return v;
 }
 
-// A NaN abscissa is clamped like any other value (np.interp would return NaN): callers that must
-// notice it test their argument themselves; in the integrator a NaN velocity has already made
-// the position NaN.
-// SCALAR_BOUNDS: the view's x0 / xlast sit in scalar registers (descriptor passed as a kernel
-// argument), so they can be the instruction's scalar operand directly.
-template <bool SCALAR_BOUNDS = false>
-NXC_DEV double lut_interp(const LutView &t, double xin)
+// The cell of x: v_cvt_i32_f64 saturates (and turns NaN into 0), which the clamp relies on; as
+// the bare instruction because a C++ double -> int cast of an out-of-range value is undefined.
+NXC_DEV int lut_cell(const LutView &t, double x)
 {
-    // Clamping to [x0, xlast] reproduces np.interp's end values exactly: at x0 record 0 gives
-    // slope*0 + fp[0]; the last record has slope 0.
-    // fmax/fmin as the bare instructions: through the builtins the compiler first canonicalises
-    // the (wave-uniform, never signalling) table bounds with an extra v_max_f64 each, every call
-    double x;
-    if (SCALAR_BOUNDS) {
-        asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(xin), "s"(t.x0));
-        asm("v_min_f64 %0, %1, %2" : "=v"(x) : "v"(x), "s"(t.xlast));
-    } else {
-        asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(xin), "v"(t.x0));
-        asm("v_min_f64 %0, %1, %2" : "=v"(x) : "v"(x), "v"(t.xlast));
-    }
-    int c = (int)((x - t.x0) * t.inv_w);
-    c = c < t.ncell ? c : t.ncell - 1;
-    int j = lds_u16(t.cell + 2 * c);
-    // rows j and j + 1 of both arrays: two address computations, the +16 is an immediate offset
-    // (row n is a sentinel {+inf, +inf} / {f_last, 0}, so j + 1 needs no clamp)
-    const int ra = t.rec + 16 * j, rb = ra + (t.fs - t.rec);
+    const double s = (x - t.xbase) * t.inv_w;
+    int c;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(c) : "v"(s));
+    c = c < 0 ? 0 : c;
+    return c > t.top ? t.top : c;
+}
+
+NXC_DEV double lut_interp(const LutView &t, double x)
+{
+    int r = lds_u16(t.cell + 2 * lut_cell(t, x));
+    // rows r and r + 1 of both arrays: two address computations, the +16 is an immediate offset
+    const int ra = t.rec + 16 * r, rb = ra + (t.fs - t.rec);
     const double2 a0 = lds_f64x2(ra), a1 = lds_f64x2(ra + 16);
     const double2 b0 = lds_f64x2(rb), b1 = lds_f64x2(rb + 16);
-    const bool in0 = (x >= a0.x) && (x < a0.y);
-    const bool in1 = (x >= a1.x) && (x < a1.y);
-    LutRec r;
-    r.xp = in0 ? a0.x : a1.x;
-    r.fp = in0 ? b0.x : b1.x;
-    r.sl = in0 ? b0.y : b1.y;
-    if (__builtin_expect(!(in0 || in1), 0)) {  // rare: walk to the interval
-        while (j > 0 && x < lds_f64(t.rec + 16 * j)) --j;
-        while (x >= lds_f64(t.rec + 16 * j + 8)) ++j;
-        const double2 aw = lds_f64x2(t.rec + 16 * j), bw = lds_f64x2(t.fs + 16 * j);
-        r.xp = aw.x; r.fp = bw.x; r.sl = bw.y;
+    const bool in0 = x < a0.y, in1 = x < a1.y;          // xp[r] <= x is built into the cell table
+    double xp = in0 ? a0.x : a1.x;
+    double fp = in0 ? b0.x : b1.x;
+    double sl = in0 ? b0.y : b1.y;
+    if (__builtin_expect(!(in0 || in1), 0)) {            // rare (and NaN): walk up to the interval
+        r += 1;
+        while (r < t.last && x >= lds_f64(t.rec + 16 * r + 8)) ++r;   // ends at the sentinel
+        const double2 aw = lds_f64x2(t.rec + 16 * r), bw = lds_f64x2(t.fs + 16 * r);
+        xp = aw.x; fp = bw.x; sl = bw.y;
     }
-    return r.sl * (x - r.xp) + r.fp;
+    return sl * (x - xp) + fp;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -149,7 +145,9 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
     if (FULL || F.grav) {                                 // state.py:19-21
         const double s2 = (x * x + y * y) + z * z;
         const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
-        if (s2 > 0x1p-130 && s2 < 0x1p+130) {
+        // 2^-130 <= s2 < 2^+130, read off the exponent field (one integer subtract + compare; a
+        // NaN or negative s2 fails it)
+        if ((unsigned)(__double2hiint(s2) - 0x37d00000) < (unsigned)(0x48100000 - 0x37d00000)) {
             // r in 2^+-65, r^3 in 2^+-195: the un-wrapped sqrt / division chains are exact here;
             // one refined reciprocal serves the three quotients
             const double r3 = nxc_cube(nxc_sqrt_mid(s2));
@@ -168,7 +166,7 @@ NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, d
         const double vv = vy + F.vrplanet;
         // interp * out_of_shadow: the product with False is a zero whose sign cannot matter in
         // gy + ry
-        const double a = lut_interp<true>(T, vv);
+        const double a = lut_interp(T, vv);
         ry = lit ? a : 0.0;
     }
     ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
@@ -337,6 +335,8 @@ struct ImageK {            // kernel-argument scalars of nxc_image_desc
     double vrplanet, apix_cm2;
     int quantity, n_lines, downcast_f32, dbg;   // dbg: timing experiments only (0 = normal)
     int nx, nz;
+    int x_is_x, pad_;     // M = [[1,0,0],[0,*,*],[0,*,*]]: the observer's x axis is the Sun frame's
+                          // (every sub-observer point on the x = 0 meridian, the default included)
     double x_lo, x_inv_step, z_lo, z_inv_step;   // only to seed the edge search
     int64_t xedges_off, zedges_off;              // byte offsets of the edge arrays in the blob
     LutDesc line[4];
@@ -580,16 +580,15 @@ NXC_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 struct ImageRegs {
     double vrplanet;
     double x_lo, x_hi, x_inv_step, z_lo, z_hi, z_inv_step;
-    int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg;
+    int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg, x_is_x;
 };
 
 NXC_DEV LutView uniform_view(const LutDesc &d)
 {
     LutView v = lut_view(d);
     v.rec = wave_uniform(v.rec); v.fs = wave_uniform(v.fs); v.cell = wave_uniform(v.cell);
-    v.n = wave_uniform(v.n); v.ncell = wave_uniform(v.ncell);
-    v.x0 = wave_uniform(v.x0); v.xlast = wave_uniform(v.xlast); v.inv_w = wave_uniform(v.inv_w);
-    v.f_first = 0.0; v.f_last = 0.0;
+    v.top = wave_uniform(v.top); v.last = wave_uniform(v.last);
+    v.xbase = wave_uniform(v.xbase); v.inv_w = wave_uniform(v.inv_w);
     return v;
 }
 
@@ -603,6 +602,7 @@ NXC_DEV ImageRegs image_regs(const ImageK &G)
     R.z_lo = lds_f64(R.zedges); R.z_hi = lds_f64(R.zedges + 8 * R.nz);
     R.x_inv_step = G.x_inv_step; R.z_inv_step = G.z_inv_step;
     R.quantity = G.quantity; R.n_lines = G.n_lines; R.downcast = G.downcast_f32;
+    R.x_is_x = wave_uniform(G.x_is_x);
 #ifdef NXC_EXPERIMENT_KNOBS     // tools/ timing experiments only: the product build has no such switch
     R.dbg = G.dbg;
 #else
@@ -622,10 +622,11 @@ NXC_DEV ImageRegs image_regs(const ImageK &G)
     return R;
 }
 
-// n/d for a launch-constant d with y = nxc_recip_seed(d) precomputed: same bits as nxc_div(n, d).
+// n/d for a launch-constant d: same bits as nxc_div(n, d).  y = nxc_recip_seed(d), or NaN when d
+// is outside the middle exponent range (decided once per launch in stage_tables).
 NXC_DEV double nxc_div_const(double n, double d, double y)
 {
-    if (!(nxc_mid_range(d) && (nxc_mid_range(n) || n == 0.0))) return n / d;
+    if (!((nxc_mid_range(n) || n == 0.0) && y == y)) return n / d;
     return nxc_div_seeded(n, d, y);
 }
 
@@ -656,12 +657,7 @@ NXC_DEV double f32_round_trip(double v) { return (double)(float)v; }
 // to the two halves of one 16-byte record).  So a pixel's weight and count are added by two lanes
 // of the SAME instruction: in the first instruction lanes 0..31 add their own weight while lanes
 // 32..63 add the count of their partner lane (l - 32); the second instruction serves the upper
-// half's samples the other way round.  One request per flushed pixel instead of two.
-//
-// Each lane also keeps summing weight and count while its packet stays in one pixel and flushes
-// only when the pixel changes (a 30 s step moves a packet by about one 512^2 pixel).  The packet
-// counts stay exact; the weighted sum only changes its (already arbitrary) summation order.
-// put() and drain() are wave-cooperative: all 64 lanes must call them from uniform control flow.
+// half's samples the other way round.  One request per binned sample instead of two.
 // value held by lane l ^ 32 (v_permlane32_swap: one VALU instruction, no LDS crossbar trip)
 NXC_DEV int half_swap(int v, bool upper)
 {
@@ -669,85 +665,146 @@ NXC_DEV int half_swap(int v, bool upper)
     return upper ? (int)r[0] : (int)r[1];
 }
 
-struct PixelAcc {
-    int pix = -1;                 // nx*nz < 2^31 (checked by nxc_set_image)
-    double w = 0.0;
-    unsigned c = 0;
+// Wave-cooperative: all 64 lanes call it from uniform control flow; `has`: this lane holds a
+// sample for pixel `pix` with weight `w` (a zero weight adds only the count).
+NXC_DEV void image_add_pairs(bool has, int pix, double w, double *__restrict__ acc2)
+{
+    if (__ballot(has) == 0) return;
+    const bool upper = (threadIdx.x & 32) != 0;
+    const int ppix = half_swap(has ? pix : -1, upper);        // partner lane's pixel, -1 = none
+    const bool own = has && w != 0.0;
+    const bool partner = ppix >= 0;
+    {   // samples of lanes 0..31
+        const bool act = upper ? partner : own;
+        if (act)
+            unsafeAtomicAdd(&acc2[2ll * (upper ? ppix : pix) + (upper ? 1 : 0)], upper ? 1.0 : w);
+    }
+    {   // samples of lanes 32..63
+        const bool act = upper ? own : partner;
+        if (act)
+            unsafeAtomicAdd(&acc2[2ll * (upper ? pix : ppix) + (upper ? 0 : 1)], upper ? w : 1.0);
+    }
+}
 
-    NXC_DEV void flush_pairs(bool need, double *__restrict__ acc2)
-    {
-        if (__ballot(need) == 0) return;
-        const bool upper = (threadIdx.x & 32) != 0;
-        const int ppix = half_swap(need ? pix : -1, upper);       // partner lane's pending pixel
-        const unsigned pc = (unsigned)half_swap((int)c, upper);
-        const bool own = need && w != 0.0;                         // a zero sum adds nothing
-        const bool partner = ppix >= 0;
-        {   // samples of lanes 0..31
-            const bool act = upper ? partner : own;
-            if (act)
-                unsafeAtomicAdd(&acc2[2ll * (upper ? ppix : pix) + (upper ? 1 : 0)],
-                                upper ? (double)pc : w);
-        }
-        {   // samples of lanes 32..63
-            const bool act = upper ? own : partner;
-            if (act)
-                unsafeAtomicAdd(&acc2[2ll * (upper ? pix : ppix) + (upper ? 0 : 1)],
-                                upper ? w : (double)pc);
-        }
-    }
-    // one sample (has: this lane has one, in pixel p with weight wt)
-    NXC_DEV void put(bool has, int p, double wt, double *__restrict__ acc2)
-    {
-        flush_pairs(has && pix >= 0 && p != pix, acc2);
-        if (has) {
-            if (p != pix) { pix = p; w = 0.0; c = 0; }
-            w += wt;
-            c += 1;
-        }
-    }
-    NXC_DEV void drain(double *__restrict__ acc2)
-    {
-        flush_pairs(pix >= 0, acc2);
-        pix = -1; w = 0.0; c = 0;
-    }
-};
-
-// Weighs one sample: returns its pixel index (ix*nz + iz) and weight, or -1 if it falls outside
-// the image.  Samples outside the image skip the weight (only its finiteness assert is kept: the
-// weight is finite iff frac and the radial velocity are).
-NXC_DEV int image_weigh(const ImageK &G, const ImageRegs &R, double x, double y, double z,
-                        double vy, double frac, double &w_out, unsigned long long &nonfinite)
+// The image work of one stored sample, in two stages so that the persistent kernel can put a
+// compaction queue between them (about half the samples of the bench workload fall outside the
+// image; the second stage -- g-value lookups, divisions, atomics -- then runs with full waves):
+//   image_locate: float32 round trip, rotation, bins, occultation and shadow masks
+//                 (ModelImage.py:242-258).  Returns the pixel (ix*nz + iz) or -1, the radial
+//                 velocity for the g-value lookup and the masked fraction fw.
+//   image_weight: weight of a located sample (ModelResult.py:148-161, ModelImage.py:262); false
+//                 when it is not finite (the reference asserts, ModelResult.py:170; here the
+//                 sample is counted in `nonfinite` and never reaches a pixel).
+NXC_DEV int image_locate(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                         double vy, double frac, double &radvel_out, double &fw_out,
+                         unsigned long long &nonfinite)
 {
     if (R.downcast) {
         x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
         vy = f32_round_trip(vy); frac = f32_round_trip(frac);
     }
     const double radvel = vy + R.vrplanet;                         // ModelImage.py:242-243
-    const double xo = (G.M[0] * x + G.M[1] * y) + G.M[2] * z;      // ModelImage.py:249
-    const double yo = (G.M[3] * x + G.M[4] * y) + G.M[5] * z;
-    const double zo = (G.M[6] * x + G.M[7] * y) + G.M[8] * z;
+    double xo, yo, zo;                                             // ModelImage.py:249
+    if (R.x_is_x) {
+        // rows (1,0,0), (0,a,b), (0,c,d): the products with 1 and 0 are exact and adding a zero
+        // changes at most the sign of a zero, which nothing below can see
+        xo = x;
+        yo = G.M[4] * y + G.M[5] * z;
+        zo = G.M[7] * y + G.M[8] * z;
+    } else {
+        xo = (G.M[0] * x + G.M[1] * y) + G.M[2] * z;
+        yo = (G.M[3] * x + G.M[4] * y) + G.M[5] * z;
+        zo = (G.M[6] * x + G.M[7] * y) + G.M[8] * z;
+    }
     const int ix = bin_index(xo, R.xedges, R.nx, R.x_lo, R.x_hi, R.x_inv_step);
     const int iz = bin_index(zo, R.zedges, R.nz, R.z_lo, R.z_hi, R.z_inv_step);
     if (ix < 0 || iz < 0) {
+        // outside the image the weight is not formed; it is finite iff frac and radvel are
         if (!(__builtin_fabs(frac) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;
         return -1;
     }
     const double s_obs = xo * xo + zo * zo;                        // ModelImage.py:252-254
     const bool inview = (s_obs > 0x1.0000000000001p+0) || (yo < 0.0);
     frac = inview ? frac : frac * 0.0;
-    double w;
-    if (R.quantity == 0) {                                         // ModelResult.py:148-149
-        w = frac;
-    } else {                                                       // ModelResult.py:150-161
+    if (R.quantity != 0)                                           // ModelImage.py:257-258
+        frac = sunlit(x, y, z) ? frac : frac * 0.0;                //   * out_of_shadow
+    radvel_out = radvel;
+    fw_out = frac;
+    return ix * R.nz + iz;
+}
+
+NXC_DEV bool image_weight(const ImageK &G, const ImageRegs &R, double radvel, double fw,
+                          double &w_out)
+{
+    double w = fw;                                                 // ModelResult.py:148-149
+    if (R.quantity != 0) {                                         // ModelResult.py:150-161
         double gg = R.n_lines > 0 ? lut_interp(lut_view(G.line[0]), radvel) : 0.0;
 #pragma unroll
         for (int l = 1; l < 4; l++)
             if (l < R.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
-        const double lit = sunlit(x, y, z) ? frac : frac * 0.0;
-        w = nxc_div_const(lit * gg, 1e6, lds_header().Wt.rs_1e6);
+        w = nxc_div_const(fw * gg, 1e6, lds_header().Wt.rs_1e6);
     }
     w = nxc_div_const(w, G.apix_cm2, lds_header().Wt.rs_apix);     // ModelImage.py:262
-    if (!(__builtin_fabs(w) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;   // :170
     w_out = w;
-    return ix * R.nz + iz;
+    return (__builtin_fabs(w) <= 1.7976931348623157e308) && radvel == radvel;   // :170
 }
+
+// locate + weight + add of one sample per lane, for the kernels that need no compaction.
+// Wave-cooperative (all lanes call it; `has`: this lane offers a sample).
+NXC_DEV void image_sample(const ImageK &G, const ImageRegs &R, bool has, double x, double y,
+                          double z, double vy, double frac, double *__restrict__ acc2,
+                          unsigned long long &binned, unsigned long long &nonfinite)
+{
+    int pix = -1;
+    double radvel = 0.0, fw = 0.0, w = 0.0;
+    if (has) pix = image_locate(G, R, x, y, z, vy, frac, radvel, fw, nonfinite);
+    bool ok = pix >= 0;
+    if (ok && !image_weight(G, R, radvel, fw, w)) { nonfinite++; ok = false; }
+    binned += ok;
+    image_add_pairs(ok, pix, w, acc2);
+}
+
+// Per-wave compaction queue between image_locate and image_weight: a ring of 128 located samples
+// {pixel, radial velocity, masked fraction} in LDS.  push() appends the lanes' samples in lane
+// order (ballot + prefix rank); once 64 are waiting, pop() hands one to every lane.  All calls
+// are wave-uniform; head and tail are wave-uniform counters.
+constexpr int NXC_IMGQ_SLOTS = 128;
+constexpr int NXC_IMGQ_BYTES = NXC_IMGQ_SLOTS * (8 + 8 + 4);
+
+struct ImageQueue {
+    int head = 0, tail = 0;
+
+    NXC_DEV void push(bool has, int pix, double radvel, double fw, int qoff)
+    {
+        const unsigned long long m = __ballot(has);
+        if (m == 0) return;
+        if (has) {
+            const int lane = threadIdx.x & 63;
+            const int slot = (tail + __popcll(m & ((1ull << lane) - 1ull))) & (NXC_IMGQ_SLOTS - 1);
+            *reinterpret_cast<double *>(nxc_lds + qoff + 8 * slot) = radvel;
+            *reinterpret_cast<double *>(nxc_lds + qoff + 8 * NXC_IMGQ_SLOTS + 8 * slot) = fw;
+            *reinterpret_cast<int *>(nxc_lds + qoff + 16 * NXC_IMGQ_SLOTS + 4 * slot) = pix;
+        }
+        tail += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    NXC_DEV int waiting() const { return tail - head; }
+    // every lane below min(64, waiting) receives a sample; returns whether this lane did
+    NXC_DEV bool pop(int qoff, int &pix, double &radvel, double &fw)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = waiting() < 64 ? waiting() : 64;
+        const int lane = threadIdx.x & 63;
+        const bool mine = lane < n;
+        if (mine) {
+            const int slot = (head + lane) & (NXC_IMGQ_SLOTS - 1);
+            radvel = *reinterpret_cast<const double *>(nxc_lds + qoff + 8 * slot);
+            fw = *reinterpret_cast<const double *>(nxc_lds + qoff + 8 * NXC_IMGQ_SLOTS + 8 * slot);
+            pix = *reinterpret_cast<const int *>(nxc_lds + qoff + 16 * NXC_IMGQ_SLOTS + 4 * slot);
+        }
+        head += n;
+        __builtin_amdgcn_wave_barrier();
+        return mine;
+    }
+};

@@ -25,18 +25,21 @@ struct DevCounters {
 
 constexpr int NXC_BLOCK = 256;      // threads per workgroup of the flat kernels (4 waves)
 // The persistent kernels run ONE 12-wave workgroup per CU (3 waves per SIMD, <= 168 VGPRs): the
-// waves of a workgroup share a single LDS copy of the tables (~76 KB for Na with a 512^2 image),
-// which leaves room for the per-wave packet staging blocks inside the CU's 160 KB.
+// waves of a workgroup share a single LDS copy of the tables (~86 KB for Na with a 512^2 image),
+// which leaves room for the per-wave packet staging blocks and image queues (4.8 KB per wave)
+// inside the CU's 160 KB.
 #ifndef NXC_BLOCK_PERSIST_N          // overridable for occupancy experiments (tools/)
 #define NXC_BLOCK_PERSIST_N 768
 #endif
 #ifndef NXC_CHUNK_N
-#define NXC_CHUNK_N 64
+#define NXC_CHUNK_N 32
 #endif
 constexpr int NXC_BLOCK_PERSIST = NXC_BLOCK_PERSIST_N;
 constexpr int NXC_CHUNK = NXC_CHUNK_N;   // packets claimed from the global queue per atomic (<= 64: one per lane)
 static_assert(NXC_CHUNK >= 1 && NXC_CHUNK <= 64, "a chunk is loaded by one wave");
 constexpr int NXC_WAVE_STAGE_BYTES = NXC_CHUNK * 9 * 8;   // per-wave LDS staging: 8 columns + packet id
+// per-wave LDS of the persistent kernels: the packet staging block, then the image queue
+constexpr int NXC_WAVE_LDS_BYTES = NXC_WAVE_STAGE_BYTES + NXC_IMGQ_BYTES;
 
 // Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS, then the
 // derived per-launch constants of the header.
@@ -50,7 +53,8 @@ NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
     if (threadIdx.x == 0) {
         LdsHeader &H = lds_header_rw();
         H.Wt.rs_1e6 = nxc_recip_seed(1e6);
-        H.Wt.rs_apix = nxc_recip_seed(H.G.apix_cm2);
+        H.Wt.rs_apix = nxc_mid_range(H.G.apix_cm2) ? nxc_recip_seed(H.G.apix_cm2)
+                                                   : __builtin_nan("");
     }
     __syncthreads();
 }
@@ -145,7 +149,6 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
-    PixelAcc acc;
     unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
@@ -160,20 +163,14 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
     long long k = 0;
     int nbounce = 0;
     // The loop is wave-uniform (it runs while any lane still has steps to take) because the image
-    // accumulator is wave-cooperative; each lane works under its own predicate.
-    {
-        int p = -1;
-        double wt = 0.0;
-        if (IMAGE && alive) {
-            my_samples++;
-            p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
-            my_binned += p >= 0;
-        }
-        if (IMAGE) acc.put(p >= 0, p, wt, acc2);
+    // accumulation is wave-cooperative; each lane works under its own predicate.
+    if (IMAGE) {
+        my_samples += alive;
+        image_sample(lds_header().G, IR, alive, s[1], s[2], s[3], s[5], s[7], acc2, my_binned,
+                     my_nonfinite);
     }
     while (__ballot(alive && k < n_iter) != 0) {
-        int p = -1;
-        double wt = 0.0;
+        bool sample = false;
         if (alive && k < n_iter) {
             if (NBODY) {
                 const BodyK *Bd = &lds_header().Bd;
@@ -190,13 +187,13 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
                 for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec + k) * n + i] = s[c];
             }
             alive = s[7] > 0.0;
-            if (IMAGE && alive) {
-                my_samples++;
-                p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
-                my_binned += p >= 0;
-            }
+            sample = alive;
         }
-        if (IMAGE) acc.put(p >= 0, p, wt, acc2);
+        if (IMAGE) {
+            my_samples += sample;
+            image_sample(lds_header().G, IR, sample, s[1], s[2], s[3], s[5], s[7], acc2,
+                         my_binned, my_nonfinite);
+        }
     }
     if (valid) {
         if (final_out) {
@@ -205,7 +202,6 @@ k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
         }
         if (steps_out) steps_out[i] = k;
     }
-    if (IMAGE) acc.drain(acc2);
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -356,12 +352,13 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
-    PixelAcc acc;
+    ImageQueue queue;
     // per-lane tallies fit 32 bits (a lane makes < 2^31 trips); widened when flushed
     unsigned my_steps = 0, my_samples = 0, my_binned = 0;
     unsigned long long my_nonfinite = 0;
     WaveQueue q;
-    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
+    const int wave_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
+    const int stage_off = wave_off, imgq_off = wave_off + NXC_WAVE_STAGE_BYTES;
     bool has = false, fresh = false;
     long long id = -1;
     int k = 0, nbounce = 0;
@@ -371,12 +368,14 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     // binned (record 0), every later trip advancing one step and being binned again, so that the
     // step and the image code each appear once and run with (nearly) full waves.  A lane that is
     // neither fresh nor free holds a live packet with k < n_iter.
+    // Image: every trip locates its samples (rotation, bins, masks) and queues the ones inside
+    // the image; whenever 64 are waiting they are weighted and added by a full wave.
     for (;;) {
         const long long got = q.refill(!has, stage_off, s);
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
         if (__ballot(has) == 0) break;
         int p = -1;
-        double wt = 0.0;
+        double rv = 0.0, fw = 0.0;
         if (has) {
             if (!fresh) {
                 if (NBODY) {
@@ -394,8 +393,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             const bool live = s[7] > 0.0;
             if (IMAGE && live) {
                 my_samples++;
-                p = image_weigh(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], wt, my_nonfinite);
-                my_binned += p >= 0;
+                p = image_locate(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], rv, fw,
+                                 my_nonfinite);
             }
             if (!live || k >= n_it) {
                 const LoopK &L = lds_header().L;
@@ -408,9 +407,27 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 has = false;
             }
         }
-        if (IMAGE) acc.put(p >= 0, p, wt, acc2);      // wave-cooperative: outside `if (has)`
+        if (IMAGE) {                                  // wave-cooperative: outside `if (has)`
+            queue.push(p >= 0, p, rv, fw, imgq_off);
+            if (queue.waiting() >= 64) {
+                double w = 0.0;
+                bool ok = queue.pop(imgq_off, p, rv, fw);
+                if (ok && !image_weight(lds_header().G, IR, rv, fw, w)) { my_nonfinite++; ok = false; }
+                my_binned += ok;
+                image_add_pairs(ok, p, w, acc2);
+            }
+        }
     }
-    if (IMAGE) acc.drain(acc2);
+    if (IMAGE) {
+        while (queue.waiting() > 0) {
+            int p = -1;
+            double rv = 0.0, fw = 0.0, w = 0.0;
+            bool ok = queue.pop(imgq_off, p, rv, fw);
+            if (ok && !image_weight(lds_header().G, IR, rv, fw, w)) { my_nonfinite++; ok = false; }
+            my_binned += ok;
+            image_add_pairs(ok, p, w, acc2);
+        }
+    }
     flush_counter(&ctr->particle_steps, my_steps);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
@@ -438,7 +455,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
     unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
     WaveQueue q;
-    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_STAGE_BYTES;
+    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
     bool has = false;
     long long id = -1, it = 0;
     double s[8], hs = 1000.0;
@@ -517,23 +534,17 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 {
     stage_tables(blob, stage_bytes);
     const ImageRegs IR = image_regs(lds_header().G);
-    PixelAcc acc;
     unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
-    // wave-uniform trip count (the accumulator is wave-cooperative); the last trip is ragged
+    // wave-uniform trip count (the accumulation is wave-cooperative); the last trip is ragged
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < p;
          base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = base + threadIdx.x;
-        int pidx = -1;
-        double wt = 0.0;
-        if (i < p) {
-            my_samples++;
-            pidx = image_weigh(lds_header().G, IR, x[i], y[i], z[i], vy[i], frac[i], wt,
-                               my_nonfinite);
-            my_binned += pidx >= 0;
-        }
-        acc.put(pidx >= 0, pidx, wt, acc2);
+        const bool has = i < p;
+        my_samples += has;
+        double sx = 0, sy = 0, sz = 0, svy = 0, sf = 0;
+        if (has) { sx = x[i]; sy = y[i]; sz = z[i]; svy = vy[i]; sf = frac[i]; }
+        image_sample(lds_header().G, IR, has, sx, sy, sz, svy, sf, acc2, my_binned, my_nonfinite);
     }
-    acc.drain(acc2);
     flush_counter(&ctr->samples, my_samples);
     flush_counter(&ctr->samples_binned, my_binned);
     flush_counter(&ctr->nonfinite, my_nonfinite);
@@ -633,7 +644,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
 #pragma unroll
                 for (int l = 1; l < 4; l++)
                     if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
-                weight = nxc_div_const(frac[p] * gg, 1e6, rs_1e6);
+                weight = nxc_div_const(frac[p] * gg, 1e6, rs_1e6);   // 1e6 is mid-range
                 if (!(__builtin_fabs(weight) <= 1.7976931348623157e308) || radvel != radvel) my_nonfinite++;
                 have_w = true;
             }
