@@ -197,11 +197,21 @@ int nxc_counters_get(nxc_handle *h, nxc_counters *out);
 int nxc_last_kernel_ms(nxc_handle *h, float *ms);  /* HIP-event time of the last integrate/image launch */
 
 /* ---- f-4: initial states sampled on the device -----------------------------------------------------
- * Fills the resident packet set with n packets of the uniform-surface / flat|gaussian-speed /
- * isotropic|radial source (initial_state/source_distribution.py:47-62,141-171,198-252) using a
- * counter-based generator (Philox-4x32-10 keyed by seed; counter = first_index + i), so shards on
- * different GPUs draw disjoint, reproducible packets.  soa_out (nullable) receives the [8][n]
- * states.  Statistically equivalent to the reference's NumPy sampler, not draw-for-draw. */
+ * Fills the resident packet set with n packets of the sources of
+ * initial_state/source_distribution.py:37-283 using a counter-based generator (Philox-4x32-10
+ * keyed by seed; counter = first_index + i), so shards on different GPUs draw disjoint,
+ * reproducible packets.  soa_out (nullable) receives the [8][n] states.  Statistically equivalent
+ * to the reference's NumPy sampler, not draw-for-draw.
+ *   surface   spatial_type 0  uniform in sin(latitude) and longitude (:47-62)
+ *             spatial_type 1  'surface spot' (:96-118): accept/reject on a density map tabulated
+ *                             on linspace(0, 2 pi, map_nlon) x linspace(-pi/2, pi/2, map_nlat),
+ *                             bilinear between nodes (math/randomdeviates.py:36-83); the device
+ *                             runs the trials per packet instead of in rounds of n candidates
+ *   speed     speed_type 0/1  flat, gaussian (:141-147,169-171)
+ *             speed_type 2    inverse CDF of a tabulated flux density (maxwellian, sputtering;
+ *                             :148-168, math/randomdeviates.py:8-33): v = interp(u, speed_cdf,
+ *                             speed_v), speed_cdf non-decreasing from 0 to 1
+ *   direction angular_type 0  radial, 1 isotropic (:198-252) */
 typedef struct nxc_source_desc {
     double endtime;        /* s                                                                 */
     double exobase;        /* R                                                                 */
@@ -211,11 +221,18 @@ typedef struct nxc_source_desc {
     double unit_km;        /* planet radius                                                     */
     double sinalt0, sinalt1, az0, az1;   /* isotropic launch cone                               */
     int32_t random_time;   /* 1: t = u*endtime (variable-step runs, Output.py:138-139)          */
-    int32_t speed_type;    /* 0 flat, 1 gaussian                                                */
+    int32_t speed_type;    /* 0 flat, 1 gaussian, 2 tabulated                                   */
     int32_t angular_type;  /* 0 radial, 1 isotropic                                             */
     int32_t is_planet;     /* longitude convention (source_distribution.py:13-28)               */
     uint64_t seed;
     int64_t first_index;
+    int32_t spatial_type;  /* 0 uniform, 1 surface spot                                         */
+    int32_t reserved;
+    int64_t n_speed;       /* speed_type 2: table length (>= 2)                                 */
+    const double *speed_cdf;   /* [n_speed] non-decreasing, first 0, last 1                     */
+    const double *speed_v;     /* [n_speed] km/s                                                */
+    int64_t map_nlon, map_nlat;   /* spatial_type 1: density map dims (>= 2 each)               */
+    const double *map;     /* [map_nlon][map_nlat], >= 0                                        */
 } nxc_source_desc;
 
 int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out);

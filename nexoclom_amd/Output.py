@@ -191,25 +191,39 @@ class Output:
         return kw
 
     def source_desc(self):
-        """Fields of nxc_source_desc for these inputs (the sources the device sampler covers:
-        uniform surface; flat or gaussian speed; isotropic or radial direction)."""
+        """Keyword arguments of hip_api.Context.sample_packets for these inputs: the scalar fields
+        of nxc_source_desc plus, where the source needs them, ``speed_table`` (maxwellian /
+        sputtering: the inverse-CDF table the host sampler interpolates in,
+        math/randomdeviates.py:29-33) and ``surface_map`` (surface spot: the 361 x 181 density map
+        the host sampler rejects against, source_distribution.py:96-113)."""
+        from .source_distribution import density_cdf, spot_density_map, tabulated_speed_density
         sd, vd, ad = self.inputs.spatialdist, self.inputs.speeddist, self.inputs.angulardist
-        if sd.type != 'uniform' or vd.type not in ('flat', 'gaussian') \
+        if sd.type not in ('uniform', 'surface spot') \
+                or vd.type not in ('flat', 'gaussian', 'maxwellian', 'sputtering') \
                 or ad.type not in ('isotropic', 'radial'):
-            raise NotImplementedError("sampler='device' supports uniform / flat|gaussian / "
-                                      "isotropic|radial sources")
-        lon0, lon1 = (float(v) for v in sd.longitude)
-        if lon0 > lon1:
-            lon1 += 2*np.pi
+            raise NotImplementedError("sampler='device' supports uniform|surface spot / "
+                                      "flat|gaussian|maxwellian|sputtering / isotropic|radial "
+                                      "sources")
         d = dict(endtime=self.inputs.options.endtime.value, exobase=float(sd.exobase),
-                 sinlat0=float(np.sin(sd.latitude[0])), sinlat1=float(np.sin(sd.latitude[1])),
-                 lon0=lon0, lon1=lon1, vprob=vd.vprob.value,
-                 vwidth=(vd.delv.value if vd.type == 'flat' else vd.sigma.value),
                  unit_km=self.unit_km, random_time=int(self.inputs.options.step_size == 0),
-                 speed_type=0 if vd.type == 'flat' else 1,
                  angular_type=0 if ad.type == 'radial' else 1,
                  is_planet=int(self.planet.type == 'Planet'),
+                 sinlat0=-1.0, sinlat1=1.0, lon0=0.0, lon1=2*np.pi, vprob=0.0, vwidth=0.0,
                  sinalt0=0.0, sinalt1=1.0, az0=0.0, az1=2*np.pi)
+        if sd.type == 'uniform':
+            lon0, lon1 = (float(v) for v in sd.longitude)
+            d.update(spatial_type=0, lon0=lon0, lon1=lon1 + 2*np.pi if lon0 > lon1 else lon1,
+                     sinlat0=float(np.sin(sd.latitude[0])), sinlat1=float(np.sin(sd.latitude[1])))
+        else:
+            _, _, density = spot_density_map(float(sd.longitude), float(sd.latitude),
+                                             float(sd.sigma))
+            d.update(spatial_type=1, surface_map=density)
+        if vd.type in ('flat', 'gaussian'):
+            d.update(speed_type=0 if vd.type == 'flat' else 1, vprob=vd.vprob.value,
+                     vwidth=vd.delv.value if vd.type == 'flat' else vd.sigma.value)
+        else:
+            grid, density = tabulated_speed_density(vd, self.inputs.options.species)
+            d.update(speed_type=2, speed_table=density_cdf(grid, density))
         if ad.type == 'isotropic':
             az0, az1 = (float(v) for v in ad.azimuth)
             if az0 > az1:

@@ -189,13 +189,21 @@ int pack_lut(const double *xp, const double *fp, int64_t n, PackedLut &out, cons
         const int64_t j = std::upper_bound(xp, xp + n, first) - xp;  // nodes with xp <= first
         cell[c] = (unsigned short)j;                                  // row j = node j - 1 (0: below)
     }
-    out.desc.n = (int)n;
-    out.desc.ncell = ncell;
+    out.desc.rec = 0;                               // offsets relative to the table: placed_lut()
+    out.desc.fs = 16 * (int)rows;
+    out.desc.cell = 32 * (int)rows;
+    out.desc.top = ncell + 1;
+    out.desc.last = (int)n + 1;
     out.desc.xbase = xbase;
     out.desc.inv_w = inv_w;
-    out.desc.offset_bytes = 0;
-    out.desc.size_bytes = (int64_t)out.bytes.size();
     return NXC_OK;
+}
+
+// The descriptor of a packed table that starts at byte `base` of the LDS block.
+LutDesc placed_lut(LutDesc d, size_t base)
+{
+    d.rec += (int)base; d.fs += (int)base; d.cell += (int)base;
+    return d;
 }
 
 // Largest double x with sqrt(x) <= e (host sqrt is correctly rounded): r2 > x <=> sqrt(r2) > e,
@@ -239,7 +247,8 @@ struct nxc_handle {
     int force_cells_per_node = 16;
     std::vector<unsigned char> image_part;       // lines, then xedges, zedges
     LdsHeader header{};                          // host copy of the blob's first bytes
-    LutDesc line_local[NXC_MAX_LINES]{};
+    LutDesc line_local[NXC_MAX_LINES]{};         // relative to the table's own start ...
+    size_t line_start[NXC_MAX_LINES]{};          // ... which sits at this offset of image_part
     int64_t xedges_local = 0, zedges_local = 0;
     unsigned char *d_blob = nullptr;
     size_t blob_cap = 0, force_bytes = 0, all_bytes = 0;
@@ -251,12 +260,16 @@ struct nxc_handle {
     size_t packets_cap = 0;
     int64_t n_packets = 0;
     unsigned *d_order = nullptr;     // packet indices by decreasing launch speed (queue order)
+    double *d_queue = nullptr;       // the state columns permuted into that order
+    size_t queue_cap = 0;
     size_t order_cap = 0;
     bool have_order = false;
     int64_t first_id = 0;            // global index of resident packet 0 (RNG counter space)
     bool have_bounce = false;
     double *d_bounce = nullptr;      // spline knots + coefficients of the accommodation table
     size_t bounce_cap = 0;
+    double *d_source = nullptr;      // sampler tables: speed CDF + speeds, surface density map
+    size_t source_cap = 0;
     DevCounters *d_ctr = nullptr;
     double *d_scratch = nullptr;     // final states / generic device scratch
     size_t scratch_cap = 0;
@@ -316,12 +329,10 @@ int upload_blob(nxc_handle *h)
         return fail(NXC_ERR_ARG, "lookup tables exceed the 160 KiB LDS of a gfx950 CU");
     int rc = ensure(reinterpret_cast<void **>(&h->d_blob), &h->blob_cap, h->all_bytes);
     if (rc) return rc;
-    h->F.tab = h->force_lut.desc;
-    h->F.tab.offset_bytes = (int64_t)hb;
+    h->F.tab = placed_lut(h->force_lut.desc, hb);
     if (h->have_image) {
         for (int l = 0; l < h->G.n_lines; l++) {
-            h->G.line[l] = h->line_local[l];
-            h->G.line[l].offset_bytes += (int64_t)(hb + fb);
+            h->G.line[l] = placed_lut(h->line_local[l], hb + fb + h->line_start[l]);
         }
         h->G.xedges_off = h->xedges_local + (int64_t)(hb + fb);
         h->G.zedges_off = h->zedges_local + (int64_t)(hb + fb);
@@ -451,7 +462,7 @@ int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, doubl
     if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, h->n_packets, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)tables, h->n_packets, h->d_packets,
+                       (int64_t)tables, h->n_packets, h->have_order ? h->d_queue : h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
                        edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr, h->d_ctr,
                        NBODY ? h->d_moonpos : (const double *)nullptr);
@@ -570,7 +581,8 @@ int nxc_destroy(nxc_handle *h)
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
-                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets};
+                    h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
+                    h->d_source, h->d_queue};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -677,7 +689,7 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
         int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
         if (rc) return rc;
         h->line_local[l] = lut.desc;
-        h->line_local[l].offset_bytes = (int64_t)part.size();
+        h->line_start[l] = part.size();
         part.insert(part.end(), lut.bytes.begin(), lut.bytes.end());
     }
     h->xedges_local = (int64_t)part.size();
@@ -819,6 +831,17 @@ int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
     });
 }
 
+#ifdef NXC_EXPERIMENT_KNOBS
+extern "C" int nxc_debug_stamps(nxc_handle *h, unsigned long long out[8])
+{
+    DevCounters c;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) out[k] = c.stamp[k];
+    return NXC_OK;
+}
+#endif
+
 int nxc_counters_get(nxc_handle *h, nxc_counters *out)
 {
     if (!h || !out) return fail(NXC_ERR_ARG, "null argument");
@@ -953,6 +976,13 @@ static int order_on_device(nxc_handle *h, double k2max)
     hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
                        scale, d_hist, h->d_order);
     HIPCHK(hipGetLastError());
+    // the persistent kernels read the queue front to back: give them a contiguous copy
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_queue), &h->queue_cap,
+                     (size_t)8 * n * sizeof(double))))
+        return rc;
+    hipLaunchKernelGGL(k_order_gather, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
+                       h->d_order, h->d_queue);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->have_order = true;
     return NXC_OK;
@@ -981,13 +1011,47 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
 {
     return guarded([&]() -> int {
     if (!h || !d || n < 1) return fail(NXC_ERR_ARG, "bad arguments");
-    if (d->speed_type < 0 || d->speed_type > 1 || d->angular_type < 0 || d->angular_type > 1 ||
-        !(d->unit_km > 0) || !(d->exobase > 0))
+    if (d->speed_type < 0 || d->speed_type > 2 || d->angular_type < 0 || d->angular_type > 1 ||
+        d->spatial_type < 0 || d->spatial_type > 1 || !(d->unit_km > 0) || !(d->exobase > 0))
         return fail(NXC_ERR_ARG, "bad nxc_source_desc");
+    const bool tab_speed = d->speed_type == 2, spot = d->spatial_type == 1;
+    if (tab_speed) {
+        if (d->n_speed < 2 || d->n_speed > (1 << 24) || !d->speed_cdf || !d->speed_v)
+            return fail(NXC_ERR_ARG, "nxc_source_desc: tabulated speeds need n_speed >= 2 and both tables");
+        for (int64_t k = 0; k + 1 < d->n_speed; k++)
+            if (!(d->speed_cdf[k + 1] >= d->speed_cdf[k]))
+                return fail(NXC_ERR_ARG, "nxc_source_desc: speed_cdf must be non-decreasing");
+        if (!(d->speed_cdf[d->n_speed - 1] > d->speed_cdf[0]))
+            return fail(NXC_ERR_ARG, "nxc_source_desc: speed_cdf is flat");
+    }
+    double map_max = 0.0;
+    if (spot) {
+        if (d->map_nlon < 2 || d->map_nlat < 2 || d->map_nlon > 8192 || d->map_nlat > 8192 || !d->map)
+            return fail(NXC_ERR_ARG, "nxc_source_desc: surface spot needs a density map");
+        for (int64_t k = 0; k < d->map_nlon * d->map_nlat; k++) {
+            if (!(d->map[k] >= 0.0) || !std::isfinite(d->map[k]))
+                return fail(NXC_ERR_ARG, "nxc_source_desc: density map values must be finite and >= 0");
+            map_max = std::max(map_max, d->map[k]);
+        }
+        if (!(map_max > 0.0)) return fail(NXC_ERR_ARG, "nxc_source_desc: density map is all zero");
+    }
     HIPCHK(hipSetDevice(h->device));
     const size_t bytes = (size_t)8 * n * sizeof(double);
     int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
     if (rc) return rc;
+    const size_t n_sp = tab_speed ? (size_t)d->n_speed : 0;
+    const size_t n_map = spot ? (size_t)(d->map_nlon * d->map_nlat) : 0;
+    if (n_sp + n_map) {
+        if ((rc = ensure(reinterpret_cast<void **>(&h->d_source), &h->source_cap,
+                         (2 * n_sp + n_map) * sizeof(double))))
+            return rc;
+        if (n_sp) {
+            HIPCHK(hipMemcpyAsync(h->d_source, d->speed_cdf, n_sp * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->d_source + n_sp, d->speed_v, n_sp * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        if (n_map)
+            HIPCHK(hipMemcpyAsync(h->d_source + 2 * n_sp, d->map, n_map * 8, hipMemcpyHostToDevice, h->stream));
+    }
     SourceK K{};
     K.endtime = d->endtime; K.exobase = d->exobase; K.sinlat0 = d->sinlat0; K.sinlat1 = d->sinlat1;
     K.lon0 = d->lon0; K.lon1 = d->lon1; K.vprob = d->vprob; K.vwidth = d->vwidth;
@@ -995,16 +1059,35 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     K.az1 = d->az1; K.random_time = d->random_time; K.speed_type = d->speed_type;
     K.angular_type = d->angular_type; K.is_planet = d->is_planet; K.seed = d->seed;
     K.first_index = d->first_index;
+    K.spatial_type = d->spatial_type; K.n_speed = (int)n_sp;
+    K.map_nlon = spot ? (int)d->map_nlon : 0; K.map_nlat = spot ? (int)d->map_nlat : 0;
+    K.map_max = map_max;
+    K.speed_cdf = h->d_source; K.speed_v = h->d_source + n_sp; K.map = h->d_source + 2 * n_sp;
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_sample, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0, h->stream, K,
-                       n, h->d_packets);
+                       n, h->d_packets, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     h->n_packets = n;
     h->rows_total = -1;
     h->first_id = d->first_index;
-    const double vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
-                                            : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
+    DevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (c.unfinished)
+        return fail(NXC_ERR_ARG, "nxc_packets_sample: " + std::to_string(c.unfinished) +
+                                 " packets found no launch point in the density map (is it "
+                                 "almost everywhere zero?)");
+    double vmax;
+    if (tab_speed) {
+        vmax = 0.0;
+        for (size_t k = 0; k < n_sp; k++) vmax = std::max(vmax, std::fabs(d->speed_v[k]));
+        vmax /= d->unit_km;
+    } else {
+        vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
+                                   : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
+    }
     if ((rc = order_on_device(h, vmax * vmax))) return rc;
     if (soa_out) HIPCHK(hipMemcpyAsync(soa_out, h->d_packets, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1236,7 +1319,7 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     if ((rc = persistent_grid(h, k_var, BLOCK_PERSIST, lds, n, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_var, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)h->force_bytes, n, h->d_packets,
+                       (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge, (long long)max_steps,
                        d_final, d_hs, h->d_ctr);
     HIPCHK(hipGetLastError());
@@ -1310,8 +1393,7 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
         PackedLut lut;
         int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
         if (rc) return rc;
-        K.line[l] = lut.desc;
-        K.line[l].offset_bytes = (int64_t)blob.size();
+        K.line[l] = placed_lut(lut.desc, blob.size());
         blob.insert(blob.end(), lut.bytes.begin(), lut.bytes.end());
     }
     const size_t stage_bytes = blob.size();

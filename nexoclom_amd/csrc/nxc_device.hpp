@@ -38,14 +38,18 @@
 // INFINITE x gives NaN where np.interp gives the end value (0 * inf) -- callers treat a
 // non-finite state as an error anyway.
 // ---------------------------------------------------------------------------------------------
-struct LutDesc {          // host-filled, passed by value in kernel arguments
-    int n;                // number of nodes (rows = n + 2)
-    int ncell;            // uniform cells over [xp[0], xp[n-1]] (cell entries = ncell + 2)
+// A table as the kernels see it: byte offsets of its three arrays inside the LDS block (the host
+// resolves them when it places the table in the blob, so a lookup adds nothing up), the index of
+// the last cell entry and of the sentinel row, and the cell transform.
+struct LutDesc {          // host-filled; in kernel arguments and in the LDS header
+    int rec, fs, cell;    // {xp, xn} pairs, {fp, slope} pairs, cell index
+    int top;              // ncell + 1: the last cell entry
+    int last;             // n + 1: the sentinel row
+    int pad_;
     double xbase;         // xp[0] - (xp[n-1] - xp[0]) / ncell
     double inv_w;         // ncell / (xp[n-1] - xp[0])
-    int64_t offset_bytes; // byte offset of this table inside the packed table blob (32-aligned)
-    int64_t size_bytes;   // bytes of this table in the blob (multiple of 32)
 };
+typedef LutDesc LutView;
 
 // All tables live in the workgroup's dynamic LDS block; they are addressed by byte offset from
 // its base so that every access is visibly an LDS (ds_read) access to the compiler.
@@ -65,24 +69,7 @@ NXC_DEV double2 lds_f64x2(int byte_off)
     return *reinterpret_cast<const double2 *>(nxc_lds + byte_off);
 }
 
-struct LutView {          // byte offsets into the LDS block
-    int rec, fs, cell;    // {xp, xn} pairs, {fp, slope} pairs, cell index
-    int top;              // ncell + 1: the last cell entry
-    int last;             // n + 1: the sentinel row
-    double xbase, inv_w;
-};
-
-NXC_DEV LutView lut_view(const LutDesc &d)
-{
-    LutView v;
-    v.rec = (int)d.offset_bytes;
-    v.fs = v.rec + 16 * (d.n + 2);
-    v.cell = v.rec + 32 * (d.n + 2);
-    v.top = d.ncell + 1;
-    v.last = d.n + 1;
-    v.xbase = d.xbase; v.inv_w = d.inv_w;
-    return v;
-}
+NXC_DEV const LutView &lut_view(const LutDesc &d) { return d; }
 
 // The cell of x: v_cvt_i32_f64 saturates (and turns NaN into 0), which the clamp relies on; as
 // the bare instruction because a C++ double -> int cast of an out-of-range value is undefined.
@@ -95,25 +82,55 @@ NXC_DEV int lut_cell(const LutView &t, double x)
     return c > t.top ? t.top : c;
 }
 
-NXC_DEV double lut_interp(const LutView &t, double x)
+// A lookup in two halves, so that a caller can put independent arithmetic between the LDS reads
+// and their first use (the two dependent round trips then run under that arithmetic):
+//   lut_probe   cell -> rows r and r + 1 of both arrays (four ds_read_b128; the +16 is an
+//               immediate offset)
+//   lut_finish  select the row, walk in the rare miss, interpolate
+struct LutProbe {
+    double x;
+    int r;
+    double2 a0, a1, b0, b1;
+};
+
+NXC_DEV void lut_probe_cell(const LutView &t, double x, LutProbe &p)
 {
-    int r = lds_u16(t.cell + 2 * lut_cell(t, x));
-    // rows r and r + 1 of both arrays: two address computations, the +16 is an immediate offset
-    const int ra = t.rec + 16 * r, rb = ra + (t.fs - t.rec);
-    const double2 a0 = lds_f64x2(ra), a1 = lds_f64x2(ra + 16);
-    const double2 b0 = lds_f64x2(rb), b1 = lds_f64x2(rb + 16);
-    const bool in0 = x < a0.y, in1 = x < a1.y;          // xp[r] <= x is built into the cell table
-    double xp = in0 ? a0.x : a1.x;
-    double fp = in0 ? b0.x : b1.x;
-    double sl = in0 ? b0.y : b1.y;
+    p.x = x;
+    p.r = lds_u16(t.cell + 2 * lut_cell(t, x));
+}
+
+NXC_DEV void lut_probe_rows(const LutView &t, LutProbe &p)
+{
+    const int ra = t.rec + 16 * p.r, rb = ra + (t.fs - t.rec);
+    p.a0 = lds_f64x2(ra); p.a1 = lds_f64x2(ra + 16);
+    p.b0 = lds_f64x2(rb); p.b1 = lds_f64x2(rb + 16);
+}
+
+NXC_DEV LutProbe lut_probe(const LutView &t, double x)
+{
+    LutProbe p;
+    lut_probe_cell(t, x, p);
+    lut_probe_rows(t, p);
+    return p;
+}
+
+NXC_DEV double lut_finish(const LutView &t, const LutProbe &p)
+{
+    const double x = p.x;
+    const bool in0 = x < p.a0.y, in1 = x < p.a1.y;      // xp[r] <= x is built into the cell table
+    double xp = in0 ? p.a0.x : p.a1.x;
+    double fp = in0 ? p.b0.x : p.b1.x;
+    double sl = in0 ? p.b0.y : p.b1.y;
     if (__builtin_expect(!(in0 || in1), 0)) {            // rare (and NaN): walk up to the interval
-        r += 1;
+        int r = p.r + 1;
         while (r < t.last && x >= lds_f64(t.rec + 16 * r + 8)) ++r;   // ends at the sentinel
         const double2 aw = lds_f64x2(t.rec + 16 * r), bw = lds_f64x2(t.fs + 16 * r);
         xp = aw.x; fp = bw.x; sl = bw.y;
     }
     return sl * (x - xp) + fp;
 }
+
+NXC_DEV double lut_interp(const LutView &t, double x) { return lut_finish(t, lut_probe(t, x)); }
 
 // ---------------------------------------------------------------------------------------------
 // Force / loss model: particle_tracking/state.py:17-74
@@ -141,33 +158,57 @@ template <bool FULL>
 NXC_DEV void state_eval(const ForceK &F, const LutView &T, double x, double y, double z, double vy,
                         double &ax, double &ay, double &az, double &ion)
 {
+    const bool lit = sunlit(x, y, z);
+    // The lookup's two dependent LDS round trips are laid under the gravity arithmetic: cell read
+    // | s2, GM r, sqrt | row reads | cube, reciprocal, quotients | select + interpolate.  The
+    // gravity code is branch-free (its full-range fall-back is a fix-up afterwards) and the
+    // scheduling barriers keep the compiler from pulling the first uses of the LDS data (and with
+    // them the s_waitcnt) up in front of the arithmetic.
+    constexpr bool OVERLAP = FULL;
+    LutProbe probe{};
+    if (FULL || F.rad) lut_probe_cell(T, vy + F.vrplanet, probe);     // state.py:27-36
     double gx = 0.0, gy = 0.0, gz = 0.0;
     if (FULL || F.grav) {                                 // state.py:19-21
         const double s2 = (x * x + y * y) + z * z;
         const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
-        // 2^-130 <= s2 < 2^+130, read off the exponent field (one integer subtract + compare; a
-        // NaN or negative s2 fails it)
-        if ((unsigned)(__double2hiint(s2) - 0x37d00000) < (unsigned)(0x48100000 - 0x37d00000)) {
-            // r in 2^+-65, r^3 in 2^+-195: the un-wrapped sqrt / division chains are exact here;
-            // one refined reciprocal serves the three quotients
-            const double r3 = nxc_cube(nxc_sqrt_mid(s2));
-            const double rinv = nxc_recip_seed(r3);
-            gx = nxc_div_seeded(nx, r3, rinv);
-            gy = nxc_div_seeded(ny, r3, rinv);
-            gz = nxc_div_seeded(nz, r3, rinv);
-        } else {
-            const double r3 = nxc_cube(__builtin_sqrt(s2));
-            gx = nx / r3; gy = ny / r3; gz = nz / r3;
+        // r in 2^+-65, r^3 in 2^+-195: the un-wrapped sqrt / division chains are exact there; one
+        // refined reciprocal serves the three quotients.  Evaluated unconditionally ...
+        const double r = nxc_sqrt_mid(s2);
+        if (OVERLAP) {
+            asm volatile("" : : "v"(r), "v"(nx), "v"(ny), "v"(nz));
+            __builtin_amdgcn_sched_barrier(0);
+            lut_probe_rows(T, probe);
+        }
+        const double r3 = nxc_cube(r);
+        const double rinv = nxc_recip_seed(r3);
+        gx = nxc_div_seeded(nx, r3, rinv);
+        gy = nxc_div_seeded(ny, r3, rinv);
+        gz = nxc_div_seeded(nz, r3, rinv);
+        if (OVERLAP) {
+            // a use of the quotients HERE: without it the compiler sinks the gravity block below
+            // the lookup's rare-miss branch, i.e. behind the LDS waits it is meant to cover
+            asm volatile("" : : "v"(gx), "v"(gy), "v"(gz));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const bool lit = sunlit(x, y, z);
+    if (!OVERLAP && (FULL || F.rad)) lut_probe_rows(T, probe);
     double ry = 0.0;
-    if (FULL || F.rad) {                                  // state.py:27-36
-        const double vv = vy + F.vrplanet;
+    if (FULL || F.rad) {
         // interp * out_of_shadow: the product with False is a zero whose sign cannot matter in
         // gy + ry
-        const double a = lut_interp(T, vv);
+        const double a = lut_finish(T, probe);
         ry = lit ? a : 0.0;
+    }
+    if (FULL || F.grav) {
+        const double s2 = (x * x + y * y) + z * z;
+        const double nx = F.GM * x, ny = F.GM * y, nz = F.GM * z;
+        // ... and replaced by the compiler's full-range sequences when s2 is not in
+        // [2^-130, 2^+130) (exponent field: one integer subtract + compare; NaN fails it too)
+        if (__builtin_expect(!((unsigned)(__double2hiint(s2) - 0x37d00000) <
+                               (unsigned)(0x48100000 - 0x37d00000)), 0)) {
+            const double r3s = nxc_cube(__builtin_sqrt(s2));
+            gx = nx / r3s; gy = ny / r3s; gz = nz / r3s;
+        }
     }
     ax = gx;                        // state.py:41 adds 0.0 here: only the sign of a zero differs
     ay = gy + ry;
@@ -583,15 +624,6 @@ struct ImageRegs {
     int xedges, zedges, nx, nz, quantity, n_lines, downcast, dbg, x_is_x;
 };
 
-NXC_DEV LutView uniform_view(const LutDesc &d)
-{
-    LutView v = lut_view(d);
-    v.rec = wave_uniform(v.rec); v.fs = wave_uniform(v.fs); v.cell = wave_uniform(v.cell);
-    v.top = wave_uniform(v.top); v.last = wave_uniform(v.last);
-    v.xbase = wave_uniform(v.xbase); v.inv_w = wave_uniform(v.inv_w);
-    return v;
-}
-
 NXC_DEV ImageRegs image_regs(const ImageK &G)
 {
     ImageRegs R;
@@ -738,10 +770,22 @@ NXC_DEV bool image_weight(const ImageK &G, const ImageRegs &R, double radvel, do
 {
     double w = fw;                                                 // ModelResult.py:148-149
     if (R.quantity != 0) {                                         // ModelResult.py:150-161
-        double gg = R.n_lines > 0 ? lut_interp(lut_view(G.line[0]), radvel) : 0.0;
+        // the lines' lookups are issued together (cells, then rows, then the selects) so that
+        // their LDS round trips overlap instead of running one table after the other
+        double gg = 0.0;
+        if (R.n_lines == 2) {
+            const LutView v0 = lut_view(G.line[0]), v1 = lut_view(G.line[1]);
+            LutProbe p0, p1;
+            lut_probe_cell(v0, radvel, p0); lut_probe_cell(v1, radvel, p1);
+            lut_probe_rows(v0, p0); lut_probe_rows(v1, p1);
+            const double g0 = lut_finish(v0, p0);
+            gg = g0 + lut_finish(v1, p1);
+        } else {
+            gg = R.n_lines > 0 ? lut_interp(lut_view(G.line[0]), radvel) : 0.0;
 #pragma unroll
-        for (int l = 1; l < 4; l++)
-            if (l < R.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
+            for (int l = 1; l < 4; l++)
+                if (l < R.n_lines) gg += lut_interp(lut_view(G.line[l]), radvel);
+        }
         w = nxc_div_const(fw * gg, 1e6, lds_header().Wt.rs_1e6);
     }
     w = nxc_div_const(w, G.apix_cm2, lds_header().Wt.rs_apix);     // ModelImage.py:262

@@ -21,7 +21,26 @@
 struct DevCounters {
     unsigned long long particle_steps, samples, samples_binned, nonfinite, bad_step, neg_frac,
         unfinished, queue_head;
+#ifdef NXC_EXPERIMENT_KNOBS     // diagnostic build only: summed s_memtime shares of the loop segments
+    unsigned long long stamp[8];
+#endif
 };
+
+#ifdef NXC_EXPERIMENT_KNOBS
+// In-kernel stamp (cdna_hip_programming.md, "In-kernel stamps"): one asm statement, fenced by
+// scheduling barriers.  Diagnostic builds only; the product build has none.
+NXC_DEV unsigned long long nxc_stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define NXC_STAMP(k) do { const unsigned long long t_ = nxc_stamp(); seg[k] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define NXC_STAMP(k) do { } while (0)
+#endif
 
 constexpr int NXC_BLOCK = 256;      // threads per workgroup of the flat kernels (4 waves)
 // The persistent kernels run ONE 12-wave workgroup per CU (3 waves per SIMD, <= 168 VGPRs): the
@@ -272,21 +291,32 @@ k_const_rows(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_byt
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave-level packet queue.  A wave claims NXC_CHUNK consecutive packet indices with one atomicAdd
-// on the global head and immediately copies their 8 state columns into its own LDS staging block
-// (coalesced: lane l loads packet base+l).  Lanes whose packet has died are then served from that
-// block in lane order (prefix rank over the ballot) with LDS reads only, so the steady-state loop
-// contains no global load and never has to wait (in-order vmcnt) behind its own in-flight image
-// atomics.  All control flow here is wave-uniform.  Returns the packet index or -1; on success
-// the lane's state is in s[].
-// The queue is walked in the order of `order` (packet indices sorted by decreasing launch speed,
-// built at upload): long-lived packets start first and the short-lived ones fill the lanes at
-// the end, which shortens the tail where few lanes still hold a packet (longest-processing-time
-// first).  The order changes nothing in any packet's result.
+// Wave-level packet queue.  A wave claims NXC_CHUNK consecutive queue positions with one atomicAdd
+// on the global head and copies their 8 state columns into its own LDS staging block (coalesced:
+// lane l loads position base + l).  Lanes whose packet has died are then served from that block in
+// lane order (prefix rank over the ballot) with LDS reads only, so the steady-state loop contains
+// no global load and never has to wait (in-order vmcnt) behind its own in-flight image atomics.
+// All control flow here is wave-uniform.  Returns the packet index or -1; on success the lane's
+// state is in s[].
+// The queue holds the packets in decreasing launch speed (nxc_api.hip: order_on_device sorts the
+// indices and writes a permuted copy of the state columns, so a chunk is contiguous in memory;
+// `ids` maps queue position -> packet index, null = identity): long-lived packets start first and
+// the short-lived ones fill the lanes at the end, which shortens the tail where few lanes still
+// hold a packet (longest-processing-time first).  The order changes nothing in any packet's
+// result.
+// The claim for the NEXT chunk is issued as soon as the current one is loaded, so the returning
+// atomic's round trip runs under that chunk's packets; a wave leaves only after the claim it
+// holds turned out to lie beyond the queue's end, so no claimed chunk is ever dropped.
 struct WaveQueue {
-    long long c_base = 0;
+    long long pending = 0;      // lane 0: queue position claimed for the next reload
     int c_pos = 0, c_cnt = 0;
     bool drained = false;
+
+    NXC_DEV void start()
+    {
+        if ((threadIdx.x & 63) == 0)
+            pending = (long long)atomicAdd(lds_header().L.head, (unsigned long long)NXC_CHUNK);
+    }
 
     NXC_DEV long long refill(bool need, int stage_off, double (&s)[8])
     {
@@ -303,21 +333,19 @@ struct WaveQueue {
                 const LoopK &L = lds_header().L;
                 const long long n = L.n;
                 const double *__restrict__ soa0 = L.soa0;
-                const unsigned *__restrict__ order = L.order;
-                long long b = 0;
-                if (lane == 0) b = (long long)atomicAdd(L.head, (unsigned long long)NXC_CHUNK);
-                b = wave_bcast0(b);
+                const unsigned *__restrict__ ids = L.order;
+                const long long b = wave_bcast0(pending);
                 if (b >= n) { drained = true; break; }
-                c_base = b;
                 c_cnt = (b + NXC_CHUNK <= n) ? NXC_CHUNK : (int)(n - b);
                 c_pos = 0;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane < c_cnt) {
-                    const long long src = order ? (long long)order[b + lane] : b + lane;
+                    const long long src = b + lane;
 #pragma unroll
                     for (int c = 0; c < 8; c++) stage[c * NXC_CHUNK + lane] = soa0[c * n + src];
-                    stage[8 * NXC_CHUNK + lane] = __longlong_as_double(src);
+                    stage[8 * NXC_CHUNK + lane] = __longlong_as_double(ids ? (long long)ids[src] : src);
                 }
+                if (lane == 0) pending = (long long)atomicAdd(L.head, (unsigned long long)NXC_CHUNK);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -357,6 +385,11 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     unsigned my_steps = 0, my_samples = 0, my_binned = 0;
     unsigned long long my_nonfinite = 0;
     WaveQueue q;
+    q.start();
+    // per-packet outputs are rare (parity tests, the rows protocol): one wave-uniform flag keeps
+    // the bench's loop from looking the pointers up every time a packet ends
+    const bool want_out = __builtin_amdgcn_readfirstlane(
+        (final_out != nullptr || steps_out != nullptr) ? 1 : 0) != 0;
     const int wave_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
     const int stage_off = wave_off, imgq_off = wave_off + NXC_WAVE_STAGE_BYTES;
     bool has = false, fresh = false;
@@ -370,10 +403,14 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     // neither fresh nor free holds a live packet with k < n_iter.
     // Image: every trip locates its samples (rotation, bins, masks) and queues the ones inside
     // the image; whenever 64 are waiting they are weighted and added by a full wave.
+#ifdef NXC_EXPERIMENT_KNOBS
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = nxc_stamp();
+#endif
     for (;;) {
         const long long got = q.refill(!has, stage_off, s);
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
         if (__ballot(has) == 0) break;
+        NXC_STAMP(0);                                  // refill
         int p = -1;
         double rv = 0.0, fw = 0.0;
         if (has) {
@@ -389,6 +426,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 }
                 k++; my_steps++;
             }
+            NXC_STAMP(1);                              // step + fate
             fresh = false;
             const bool live = s[7] > 0.0;
             if (IMAGE && live) {
@@ -396,28 +434,39 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 p = image_locate(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], rv, fw,
                                  my_nonfinite);
             }
+            NXC_STAMP(2);                              // locate
             if (!live || k >= n_it) {
-                const LoopK &L = lds_header().L;
-                if (double *fo = L.final_out) {
-                    const long long np = L.n;
+                if (want_out) {
+                    const LoopK &L = lds_header().L;
+                    if (double *fo = L.final_out) {
+                        const long long np = L.n;
 #pragma unroll
-                    for (int c = 0; c < 8; c++) fo[c * np + id] = s[c];
+                        for (int c = 0; c < 8; c++) fo[c * np + id] = s[c];
+                    }
+                    if (long long *so = L.steps_out) so[id] = k;
                 }
-                if (long long *so = L.steps_out) so[id] = k;
                 has = false;
             }
         }
+        NXC_STAMP(3);                                  // final-state bookkeeping
         if (IMAGE) {                                  // wave-cooperative: outside `if (has)`
             queue.push(p >= 0, p, rv, fw, imgq_off);
+            NXC_STAMP(4);                              // push
             if (queue.waiting() >= 64) {
                 double w = 0.0;
                 bool ok = queue.pop(imgq_off, p, rv, fw);
                 if (ok && !image_weight(lds_header().G, IR, rv, fw, w)) { my_nonfinite++; ok = false; }
                 my_binned += ok;
+                NXC_STAMP(5);                          // pop + weight
                 image_add_pairs(ok, p, w, acc2);
+                NXC_STAMP(6);                          // atomics
             }
         }
     }
+#ifdef NXC_EXPERIMENT_KNOBS
+    if ((threadIdx.x & 63) == 0)
+        for (int c = 0; c < 8; c++) atomicAdd(&ctr->stamp[c], seg[c]);
+#endif
     if (IMAGE) {
         while (queue.waiting() > 0) {
             int p = -1;
@@ -455,6 +504,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
     unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
     WaveQueue q;
+    q.start();
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
     bool has = false;
     long long id = -1, it = 0;
@@ -686,12 +736,52 @@ struct SourceK {
     int random_time, speed_type, angular_type, is_planet;
     unsigned long long seed;
     long long first_index;
+    int spatial_type, n_speed, map_nlon, map_nlat;
+    double map_max;                      // accept/reject ceiling = max of the density map
+    const double *speed_cdf, *speed_v, *map;
 };
 
+// np.interp(x, xp, fp) for a non-decreasing xp in global memory: bisection for the last node
+// <= x, then slope*(x - xp[j]) + fp[j] (numpy compiled_base.c arr_interp).
+NXC_DEV double interp_global(const double *__restrict__ xp, const double *__restrict__ fp, int n,
+                             double x)
+{
+    if (!(x > xp[0])) return fp[0];
+    if (!(x < xp[n - 1])) return fp[n - 1];
+    int lo = 0, hi = n - 1;                      // xp[lo] <= x < xp[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (x >= xp[mid]) lo = mid; else hi = mid;
+    }
+    const double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (x - xp[lo]) + fp[lo];
+}
+
+// Bilinear value of the density map at (lon, lat) inside its grid (the linear interpn of
+// math/randomdeviates.py:66); weights in the order ((1-tx)(1-ty) f00 + (1-tx) ty f01) +
+// (tx (1-ty) f10 + tx ty f11).
+NXC_DEV double map_bilinear(const SourceK &K, double lon, double lat)
+{
+    const double TWO_PI = 6.283185307179586, HALF_PI = 1.5707963267948966;
+    const double gx = lon / (TWO_PI / (K.map_nlon - 1));
+    const double gy = (lat + HALF_PI) / (3.141592653589793 / (K.map_nlat - 1));
+    int i = (int)gx, j = (int)gy;
+    i = i < 0 ? 0 : (i > K.map_nlon - 2 ? K.map_nlon - 2 : i);
+    j = j < 0 ? 0 : (j > K.map_nlat - 2 ? K.map_nlat - 2 : j);
+    const double tx = gx - (double)i, ty = gy - (double)j;
+    const double *row0 = K.map + (long long)i * K.map_nlat + j, *row1 = row0 + K.map_nlat;
+    return ((1.0 - tx) * (1.0 - ty) * row0[0] + (1.0 - tx) * ty * row0[1]) +
+           (tx * (1.0 - ty) * row1[0] + tx * ty * row1[1]);
+}
+
+constexpr int NXC_SPOT_MAX_TRIALS = 4096;   // a packet that never passes keeps its last candidate
+constexpr unsigned NXC_SPOT_BLOCK0 = 16;    // Philox draw blocks 16 + 2t, 17 + 2t of trial t
+
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_sample(SourceK K, int64_t n, double *__restrict__ soa)
+k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict__ ctr)
 {
     const double TWO_PI = 6.283185307179586;
+    unsigned long long my_unfinished = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long gi = (unsigned long long)(K.first_index + i);
@@ -700,9 +790,24 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa)
         philox_pair(gi, 1, NXC_STREAM_SOURCE, K.seed, ulon, uspd);
         philox_pair(gi, 2, NXC_STREAM_SOURCE, K.seed, ualt, uaz);
         const double time = K.random_time ? ut * K.endtime : K.endtime;       // Output.py:136-139
-        const double sinlat = K.sinlat0 + (K.sinlat1 - K.sinlat0) * ulat;     // :51-53
-        const double lat = asin(sinlat);
-        double lon = fmod(K.lon0 + (K.lon1 - K.lon0) * ulon, TWO_PI);         // :56-62
+        double lat, lon;
+        if (K.spatial_type == 0) {                                             // uniform :51-62
+            lat = asin(K.sinlat0 + (K.sinlat1 - K.sinlat0) * ulat);
+            lon = fmod(K.lon0 + (K.lon1 - K.lon0) * ulon, TWO_PI);
+        } else {                                                               // surface spot :96-118
+            bool accepted = false;
+            lon = 0.0; lat = 0.0;
+            for (int t = 0; t < NXC_SPOT_MAX_TRIALS && !accepted; t++) {
+                double ux, uy, uf, unused;
+                philox_pair(gi, NXC_SPOT_BLOCK0 + 2u * (unsigned)t, NXC_STREAM_SOURCE, K.seed, ux, uy);
+                philox_pair(gi, NXC_SPOT_BLOCK0 + 2u * (unsigned)t + 1u, NXC_STREAM_SOURCE, K.seed,
+                            uf, unused);
+                lon = ux * TWO_PI;
+                lat = uy * 3.141592653589793 - 1.5707963267948966;
+                accepted = uf * K.map_max < map_bilinear(K, lon, lat);
+            }
+            my_unfinished += !accepted;
+        }
         const double clat = cos(lat);
         const double x0 = (K.is_planet ? 1.0 : -1.0) * K.exobase * sin(lon) * clat;   // :12-28
         const double y0 = -K.exobase * cos(lon) * clat;
@@ -710,11 +815,13 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa)
         double v;
         if (K.speed_type == 0) {                                               // flat :169-171
             v = uspd * 2 * K.vwidth + K.vprob - K.vwidth;
-        } else {                                                               // gaussian :141-147
+        } else if (K.speed_type == 1) {                                        // gaussian :141-147
             double g0, g1;
             philox_pair(gi, 3, NXC_STREAM_SOURCE, K.seed, g0, g1);
             const double zn = sqrt(-2.0 * log(1.0 - g0)) * cos(TWO_PI * g1);
             v = K.vwidth == 0.0 ? K.vprob : zn * K.vwidth + K.vprob;
+        } else {                                                               // tabulated :148-168
+            v = interp_global(K.speed_cdf, K.speed_v, K.n_speed, uspd);
         }
         v = v / K.unit_km;                                                     // :184
         double alt, az;
@@ -737,6 +844,7 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa)
         soa[4 * n + i] = dx * v; soa[5 * n + i] = dy * v; soa[6 * n + i] = dz * v;
         soa[7 * n + i] = 1.0;
     }
+    flush_counter(&ctr->unfinished, my_unfinished);
 }
 
 // Queue order on the device: counting sort of the packet indices by decreasing |v|^2.
@@ -784,6 +892,19 @@ k_order_hist(const double *__restrict__ soa, int64_t n, double scale,
     __syncthreads();
     for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
         if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+// The state columns in queue order: out[c][q] = soa[c][order[q]].
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_order_gather(const double *__restrict__ soa, int64_t n, const unsigned *__restrict__ order,
+               double *__restrict__ out)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = order[q];
+#pragma unroll
+        for (int c = 0; c < 8; c++) out[c * n + q] = soa[c * n + i];
+    }
 }
 
 __global__ void __launch_bounds__(NXC_BLOCK)

@@ -61,7 +61,9 @@ class nxc_source_desc(C.Structure):
                 ('endtime', 'exobase', 'sinlat0', 'sinlat1', 'lon0', 'lon1', 'vprob', 'vwidth',
                  'unit_km', 'sinalt0', 'sinalt1', 'az0', 'az1')] + \
                [(k, C.c_int32) for k in ('random_time', 'speed_type', 'angular_type', 'is_planet')] + \
-               [('seed', C.c_uint64), ('first_index', C.c_int64)]
+               [('seed', C.c_uint64), ('first_index', C.c_int64), ('spatial_type', C.c_int32),
+                ('reserved', C.c_int32), ('n_speed', C.c_int64), ('speed_cdf', _dp),
+                ('speed_v', _dp), ('map_nlon', C.c_int64), ('map_nlat', C.c_int64), ('map', _dp)]
 
 
 class nxc_bounce_desc(C.Structure):
@@ -289,14 +291,28 @@ class Context:
         self._check(self.lib.nxc_packets_upload(self._h, C.c_int64(soa.shape[1]), _p(soa)))
         self.n_packets = soa.shape[1]
 
-    def sample_packets(self, n, seed, first_index=0, download=False, **src):
-        """Draw n initial states on the device (nxc_packets_sample).  ``src``: the fields of
-        nxc_source_desc except seed/first_index (see Output.source_desc)."""
+    def sample_packets(self, n, seed, first_index=0, download=False, speed_table=None,
+                       surface_map=None, **src):
+        """Draw n initial states on the device (nxc_packets_sample).  ``src``: the scalar fields
+        of nxc_source_desc except seed/first_index; ``speed_table`` = (cdf, speeds [km/s]) for
+        speed_type 2; ``surface_map`` = density array [nlon, nlat] for spatial_type 1 (see
+        Output.source_desc)."""
         d = nxc_source_desc()
         for k, v in src.items():
             setattr(d, k, v)
         d.seed = int(seed) & 0xffffffffffffffff
         d.first_index = int(first_index)
+        keep = []
+        if speed_table is not None:
+            cdf, speeds = _f64(speed_table[0]), _f64(speed_table[1])
+            if cdf.shape != speeds.shape or cdf.ndim != 1:
+                raise ValueError('speed_table must be two 1-D arrays of equal length')
+            keep += [cdf, speeds]
+            d.n_speed, d.speed_cdf, d.speed_v = len(cdf), _p(cdf), _p(speeds)
+        if surface_map is not None:
+            dens = _f64(surface_map)
+            keep.append(dens)
+            d.map_nlon, d.map_nlat, d.map = dens.shape[0], dens.shape[1], _p(dens)
         out = np.empty((8, int(n))) if download else None
         self._check(self.lib.nxc_packets_sample(self._h, C.byref(d), C.c_int64(int(n)),
                                                 _p(out) if download else None))

@@ -79,12 +79,19 @@ def MaxwellianDist(velocity, temperature, species):
     return density / np.max(density)
 
 
-def random_deviates_1d(x, f_x, num):
-    """Inverse-CDF deviates of the density f_x tabulated on x (randomdeviates.py:8-33)."""
+def density_cdf(x, f_x):
+    """(cdf, grid) of a density tabulated on x: running sum shifted to start at 0 and scaled to
+    end at 1, on an even grid over x's range (randomdeviates.py:29-32)."""
     grid = np.linspace(x.min(), x.max(), f_x.shape[0])
     cdf = f_x.cumsum()
     cdf -= cdf.min()
     cdf /= cdf.max()
+    return cdf, grid
+
+
+def random_deviates_1d(x, f_x, num):
+    """Inverse-CDF deviates of the density f_x tabulated on x (randomdeviates.py:8-33)."""
+    cdf, grid = density_cdf(x, f_x)
     return np.interp(unseeded.rand(num), cdf, grid)
 
 
@@ -169,26 +176,28 @@ def _speed_flat(out, vd, species):
     return out.randgen.random(out.npackets)*2*vd.delv.value + vd.vprob.value - vd.delv.value
 
 
-def _speed_sputtering(out, vd, species):
-    grid = np.linspace(.1, 50, 5000)
-    return random_deviates_1d(grid, sputdist(grid, vd.U.value, vd.alpha, vd.beta, species),
-                              out.npackets)
-
-
-def _speed_maxwellian(out, vd, species):
-    assert vd.temperature != 0, 'Not implemented yet'
+def tabulated_speed_density(vd, species):
+    """(velocity grid [km/s], flux density) of the 'sputtering' and 'maxwellian' speed
+    distributions on the reference's 5000-point grids (source_distribution.py:148-168)."""
+    if vd.type == 'sputtering':
+        grid = np.linspace(.1, 50, 5000)
+        return grid, sputdist(grid, vd.U.value, vd.alpha, vd.beta, species)
+    assert vd.type == 'maxwellian' and vd.temperature != 0, 'Not implemented yet'
     v_th = np.sqrt(2*vd.temperature.value*const.K_B/_mass_kg(species)) / 1e3
     grid = np.linspace(0.1, v_th*5, 5000)
-    return random_deviates_1d(grid, MaxwellianDist(grid, vd.temperature.value, species),
-                              out.npackets)
+    return grid, MaxwellianDist(grid, vd.temperature.value, species)
+
+
+def _speed_tabulated(out, vd, species):
+    return random_deviates_1d(*tabulated_speed_density(vd, species), out.npackets)
 
 
 def _speed_from_file(out, vd, species):
     raise InputError('speed_distribution', 'user-defined speed files are out of scope')
 
 
-SPEEDS = {'gaussian': _speed_gaussian, 'flat': _speed_flat, 'sputtering': _speed_sputtering,
-          'maxwellian': _speed_maxwellian, 'user defined': _speed_from_file}
+SPEEDS = {'gaussian': _speed_gaussian, 'flat': _speed_flat, 'sputtering': _speed_tabulated,
+          'maxwellian': _speed_tabulated, 'user defined': _speed_from_file}
 
 
 def speed_distribution(outputs):

@@ -460,30 +460,62 @@ def philox_uniform_pairs(index, block, stream, seed):
     return u0, u1
 
 
+def map_bilinear(dens, lon, lat):
+    """Bilinear value of a density map on linspace(0, 2 pi, nlon) x linspace(-pi/2, pi/2, nlat),
+    the weights in the kernel's order (the linear interpn of math/randomdeviates.py:66)."""
+    nlon, nlat = dens.shape
+    gx = lon/(2*np.pi/(nlon - 1))
+    gy = (lat + np.pi/2)/(np.pi/(nlat - 1))
+    i = np.clip(gx.astype(np.int64), 0, nlon - 2)
+    j = np.clip(gy.astype(np.int64), 0, nlat - 2)
+    tx, ty = gx - i, gy - j
+    return (((1.0 - tx)*(1.0 - ty)*dens[i, j] + (1.0 - tx)*ty*dens[i, j+1])
+            + (tx*(1.0 - ty)*dens[i+1, j] + tx*ty*dens[i+1, j+1]))
+
+
 def sample_x0_philox(n, seed, first_index=0, *, endtime, exobase=1.0, sinlat0=-1.0, sinlat1=1.0,
                      lon0=0.0, lon1=2*np.pi, vprob=2.5, vwidth=2.0, unit_km=2440.53,
                      sinalt0=0.0, sinalt1=1.0, az0=0.0, az1=2*np.pi, random_time=0, speed_type=0,
-                     angular_type=1, is_planet=1):
+                     angular_type=1, is_planet=1, spatial_type=0, speed_table=None,
+                     surface_map=None, max_trials=4096):
     """NumPy restatement of the device sampler (k_sample): the formulas of
-    initial_state/source_distribution.py:47-62,141-171,198-252 fed by Philox uniforms.
+    initial_state/source_distribution.py:47-62,96-118,141-171,198-252 fed by Philox uniforms.
     Returns X0 (n, 8)."""
     idx = np.arange(n, dtype=np.uint64) + np.uint64(first_index)
     ut, ulat = philox_uniform_pairs(idx, 0, 0x5a0, seed)
     ulon, uspd = philox_uniform_pairs(idx, 1, 0x5a0, seed)
     ualt, uaz = philox_uniform_pairs(idx, 2, 0x5a0, seed)
     time = ut*endtime if random_time else np.zeros(n) + endtime
-    lat = np.arcsin(sinlat0 + (sinlat1 - sinlat0)*ulat)
-    lon = np.fmod(lon0 + (lon1 - lon0)*ulon, 2*np.pi)
+    if spatial_type == 0:
+        lat = np.arcsin(sinlat0 + (sinlat1 - sinlat0)*ulat)
+        lon = np.fmod(lon0 + (lon1 - lon0)*ulon, 2*np.pi)
+    else:
+        # surface spot: per packet, trial t takes draw blocks 16 + 2t and 17 + 2t
+        dens = np.asarray(surface_map, dtype=float)
+        ceiling = dens.max()
+        lon, lat = np.zeros(n), np.zeros(n)
+        todo = np.arange(n)
+        for t in range(max_trials):
+            if len(todo) == 0:
+                break
+            ux, uy = philox_uniform_pairs(idx[todo], 16 + 2*t, 0x5a0, seed)
+            uf, _ = philox_uniform_pairs(idx[todo], 17 + 2*t, 0x5a0, seed)
+            cl, cb = ux*(2*np.pi), uy*np.pi - np.pi/2
+            lon[todo], lat[todo] = cl, cb
+            todo = todo[~(uf*ceiling < map_bilinear(dens, cl, cb))]
+        assert len(todo) == 0, 'rejection sampling did not converge'
     sign = 1.0 if is_planet else -1.0
     x0 = sign*exobase*np.sin(lon)*np.cos(lat)
     y0 = -exobase*np.cos(lon)*np.cos(lat)
     z0 = exobase*np.sin(lat)
     if speed_type == 0:
         v = uspd*2*vwidth + vprob - vwidth
-    else:
+    elif speed_type == 1:
         g0, g1 = philox_uniform_pairs(idx, 3, 0x5a0, seed)
         zn = np.sqrt(-2.0*np.log(1.0 - g0))*np.cos(2*np.pi*g1)
         v = np.zeros(n) + vprob if vwidth == 0 else zn*vwidth + vprob
+    else:
+        v = np.interp(uspd, speed_table[0], speed_table[1])
     v = v/unit_km
     if angular_type == 0:
         alt, az = np.zeros(n) + np.pi/2, np.zeros(n)

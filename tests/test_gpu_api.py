@@ -374,3 +374,67 @@ def test_rccl_refuses_two_ranks_on_one_device(ctx):
     with pytest.raises(hip_api.HipError, match='one process per GPU'):
         TwoOnOne().init_rccl(ctx)
     assert len(ctx.bus_id()) >= 7
+
+
+REF_INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'inputfiles')
+
+
+@pytest.mark.parametrize('infile', ['Na.reference.input', 'Ca.reference.input'])
+def test_device_sampler_covers_the_reference_run_sources(ctx, infile):
+    """The sources of the reference's own reference runs (tests/test_data/inputfiles/
+    {Na,Ca}.reference.input: 'surface spot' + 'maxwellian', which its system test
+    tests/system_tests/test_run_through.py:9-31 drives) on the device sampler: equal to the NumPy
+    Philox restatement to libm rounding, counter-addressed, and statistically the host sampler's
+    distributions (two-sample KS per column; the host one draws from NumPy's global generator)."""
+    import numpy.random as nprandom
+    from scipy import stats
+    inputs = Input(os.path.join(REF_INPUTS, infile))
+    n = 100000
+    out = Output(inputs, n, seed=31, integrate=False, save=False, context=ctx, sampler='device')
+    src = out.source_desc()
+    assert src['spatial_type'] == 1 and src['speed_type'] == 2
+    assert src['surface_map'].shape == (361, 181) and len(src['speed_table'][0]) == 5000
+    X = out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values
+    ref = O.sample_x0_philox(n, 31, **src)
+    np.testing.assert_allclose(X, ref, rtol=1e-11, atol=1e-14)
+    a = ctx.sample_packets(700, 31, first_index=0, download=True, **src)
+    b = ctx.sample_packets(300, 31, first_index=700, download=True, **src)
+    c = ctx.sample_packets(1000, 31, first_index=0, download=True, **src)
+    assert np.array_equal(np.concatenate([a, b], axis=1), c)
+    nprandom.seed(8)
+    host = Output(inputs, n, seed=5, integrate=False, save=False)
+    for col in ('x', 'y', 'z', 'vx', 'vy', 'vz'):
+        assert stats.ks_2samp(out.X0[col].values, host.X0[col].values).pvalue > 1e-3, col
+    speed_d = np.linalg.norm(X[:, 4:7], axis=1)
+    assert stats.ks_2samp(speed_d, host.X0.v.values).pvalue > 1e-3
+    # the spot: launch points cluster around the requested centre
+    centre = np.array([np.sin(float(inputs.spatialdist.longitude)),
+                       -np.cos(float(inputs.spatialdist.longitude)), 0.0])
+    assert (X[:, 1:4] @ centre).mean() > 0.3
+
+
+@pytest.mark.parametrize('infile', ['Na.reference.input', 'Ca.reference.input'])
+def test_reference_run_inputs_end_to_end(ctx, coracle, infile):
+    """{Na,Ca}.reference.input through Input -> ModelImage(npackets=, sampler='device'): the
+    streamed radiance image equals the C oracle run on the very packets the device drew (counts
+    exactly, brightness to 1e-11)."""
+    inputs = Input(os.path.join(REF_INPUTS, infile))
+    species = inputs.options.species
+    params = {'quantity': 'radiance', 'dims': '96,96', 'width': '12,12'}
+    img = ModelImage(inputs, params, npackets=5000, packs_per_it=2000, seed=4, context=ctx,
+                     sampler='device')
+    out = Output(inputs, 5000, seed=4, integrate=False, save=False, context=ctx, sampler='device')
+    X0 = out.X0[['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']].values
+    opt = inputs.options
+    f = H.mercury_forces(species, float(inputs.geometry.taa))
+    waves = {'Na': (5891, 5897), 'Ca': (4227,)}[species]
+    im = H.image_setup(f, 'radiance', dims=(96, 96), width=(12., 12.), species=species,
+                       wavelengths=waves)
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], 'radiance', im['g_tables'],
+                              im['xedges'], im['zedges'], downcast=True)
+    nsteps, n_iter = O.n_output_steps(opt.endtime.value, opt.step_size)
+    ref = coracle.integrate_const(f, X0, opt.step_size, n_iter, opt.outeredge, img=desc, threads=4)
+    assert img.counters['particle_steps'] == ref['work']
+    assert ref['counts'].sum() > 10000
+    assert np.array_equal(img.packet_image, ref['counts'].astype(float))
+    np.testing.assert_allclose(img.image, ref['image']*img.atoms_per_packet, rtol=1e-11)

@@ -25,10 +25,12 @@ SRC = os.path.join(ROOT, 'nexoclom_amd', 'csrc')
 
 # (file, first line, last line) -> section; filled from the sources so that edits do not shift it
 FUNCS = {
-    'nxc_device.hpp': ['lut_interp', 'sunlit', 'state_eval', 'rk5_step', 'apply_fate', 'bin_index',
-                       'flush_pairs', 'put', 'drain', 'image_weigh', 'image_regs', 'wave_uniform',
-                       'nxc_div_const', 'half_swap', 'f32_round_trip', 'lut_view', 'uniform_view',
-                       'bodies_eval', 'moon_position', 'bounce_packet'],
+    'nxc_device.hpp': ['lut_interp', 'lut_cell', 'lds_f64', 'lds_u16', 'lds_f64x2', 'sunlit',
+                       'state_eval', 'rk5_step', 'apply_fate', 'bin_index', 'image_locate',
+                       'image_weight', 'image_sample', 'image_add_pairs', 'push', 'pop', 'waiting',
+                       'image_regs', 'wave_uniform', 'nxc_div_const', 'half_swap',
+                       'f32_round_trip', 'lut_view', 'uniform_view', 'bodies_eval',
+                       'moon_position', 'bounce_packet'],
     'nxc_math.hpp': ['nxc_sqrt_mid', 'nxc_sqrt', 'nxc_recip_seed', 'nxc_div_seeded', 'nxc_div_mid',
                      'nxc_div', 'nxc_cube', 'nxc_exp', 'nxc_log', 'nxc_mid_range'],
     'nxc_kernels.hpp': ['stage_tables', 'stage_tables_and_args', 'refill', 'k_const_fused',
@@ -108,7 +110,7 @@ def main():
         return fn + ':?'
 
     # pass 1: split into basic blocks, find the cold ones
-    blocks, cur = [], {'label': 'entry', 'ins': []}
+    blocks, cur = [], {'label': 'entry', 'ins': [], 'depth': 0}
     loc = (0, 0)
     for l in text[start+1:end]:
         s = l.strip()
@@ -118,7 +120,8 @@ def main():
             continue
         if re.match(r'^\.LBB\d+_\d+:', s):
             blocks.append(cur)
-            cur = {'label': s.split(':')[0], 'ins': []}
+            m = re.search(r'Depth=(\d+)', s)
+            cur = {'label': s.split(':')[0], 'ins': [], 'depth': int(m.group(1)) if m else 0}
             continue
         if not s or s.startswith((';', '.')):
             continue
@@ -128,28 +131,33 @@ def main():
         cur['ins'].append((op, section(*loc), s))
         if op.startswith(('s_cbranch', 's_branch', 's_endpgm', 's_setpc')):
             blocks.append(cur)                 # a branch ends the block even without a label
-            cur = {'label': cur['label'] + "'", 'ins': []}
+            cur = {'label': cur['label'] + "'", 'ins': [], 'depth': cur['depth']}
     blocks.append(cur)
     cold_ops = ('v_div_scale_f64', 'v_div_fmas_f64', 'v_div_fixup_f64')
+    # depth 1 = the persistent loop's own blocks; depth >= 2 = loops inside it (queue refill, table
+    # and edge walks: rare); depth 0 = prologue / epilogue (once per wave)
     for b in blocks:
         b['cold'] = any(op in cold_ops for op, _, _ in b['ins'])
     table = collections.defaultdict(collections.Counter)
     for b in blocks:
         for op, sec, _ in b['ins']:
-            key = ('cold: ' if b['cold'] else '') + sec
-            table[key][classify(op)] += 1
+            tag = ('cold: ' if b['cold'] else 'once: ' if b['depth'] == 0
+                   else 'inner: ' if b['depth'] >= 2 else '')
+            table[tag + sec][classify(op)] += 1
     cols = ['fp64', 'transc', 'cvt', 'cmp', 'select', 'valu32', 'lds', 'vmem', 'salu']
     print(f'kernel {text[start].split(":")[0]}')
     print(f'{"section":34s}' + ''.join(f'{c:>8s}' for c in cols) + f'{"VALU":>8s}')
     tot = collections.Counter()
-    for key in sorted(table, key=lambda k: (k.startswith('cold'), -sum(table[k].values()))):
+    def rank(k):
+        return (k.split(': ')[0] if ': ' in k else '', -sum(table[k].values()))
+    for key in sorted(table, key=rank):
         row = table[key]
         valu = sum(row[c] for c in ('fp64', 'transc', 'cvt', 'cmp', 'select', 'valu32'))
         print(f'{key:34s}' + ''.join(f'{row[c]:8d}' for c in cols) + f'{valu:8d}')
-        if not key.startswith('cold'):
+        if ': ' not in key:
             tot.update(row)
     valu = sum(tot[c] for c in ('fp64', 'transc', 'cvt', 'cmp', 'select', 'valu32'))
-    print(f'{"hot total":34s}' + ''.join(f'{tot[c]:8d}' for c in cols) + f'{valu:8d}')
+    print(f'{"loop body total":34s}' + ''.join(f'{tot[c]:8d}' for c in cols) + f'{valu:8d}')
     if '--blocks' in sys.argv:
         for b in blocks:
             secs = collections.Counter(sec for _, sec, _ in b['ins'])
