@@ -197,7 +197,19 @@ def main():
 
     if hip_api.device_count() < 1:
         raise SystemExit('bench.py needs a HIP device; there is no CPU fallback')
-    ctx = hip_api.Context(pick_device(cp))
+    # every rank needs a device of its own; the ranks agree on that before anything is set up
+    ctx, err = None, ''
+    try:
+        ctx = hip_api.Context(pick_device(cp))
+    except hip_api.HipError as exc:
+        err = str(exc)
+    problems = [p.decode() for p in cp.allgather_bytes(err.encode())]
+    if any(problems):
+        if rank == 0:
+            print(json.dumps(fail_line(args, world, '; '.join(p for p in problems if p))))
+        sys.stderr.write(f'[bench rank {rank}] {err or "another rank has no device"}\n')
+        cp.close()
+        sys.exit(1)
 
     # ---- set-up (untimed): this rank's shard = chunk `rank` of the global chunk grid ----------
     (k, c0, clen, a, b), = chunk_plan(packets*world, packets, rank*packets, (rank + 1)*packets)

@@ -1315,10 +1315,12 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     int grid = 1;
     const size_t lds = persist_lds(h->force_bytes);
-    if ((rc = prep_kernel(k_var, lds))) return rc;
-    if ((rc = persistent_grid(h, k_var, BLOCK_PERSIST, lds, n, &grid))) return rc;
+    const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
+    auto kernel = full ? k_var<true> : k_var<false>;
+    if ((rc = prep_kernel(kernel, lds))) return rc;
+    if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, n, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(k_var, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
                        (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge, (long long)max_steps,
                        d_final, d_hs, h->d_ctr);

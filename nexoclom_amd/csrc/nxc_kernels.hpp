@@ -493,6 +493,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 //   errmax < 1e-7 -> errmax = 1 and h*10, which lands in the REJECT branch (errmax >= 1)  :294-300
 //   accept (errmax < 1): fate tests on r^2; the grown step is never stored  :302-327
 //   reject: stored step = max(0.95 h errmax^-0.25, 0.1 h)               :333-342
+template <bool FULL>      // FULL: gravity + radiation pressure + photo-loss known at compile time
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
       const double *__restrict__ soa0, const unsigned *__restrict__ order, double resolution, double outeredge, long long max_steps,
@@ -525,7 +526,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                     double t[8], d[8];
 #pragma unroll
                     for (int c = 0; c < 8; c++) t[c] = s[c];
-                    rk5_step<true, false>(F, T, t, h, StepW{}, d);
+                    rk5_step<true, false, FULL>(F, T, t, h, StepW{}, d);
                     my_steps++; it++;
                     const double fscale = resf + __builtin_fabs(t[7]) * resf;
                     // max over the columns; a NaN quotient must not be dropped by fmax (the

@@ -25,7 +25,7 @@ SRC = os.path.join(ROOT, 'nexoclom_amd', 'csrc')
 
 # (file, first line, last line) -> section; filled from the sources so that edits do not shift it
 FUNCS = {
-    'nxc_device.hpp': ['lut_interp', 'lut_cell', 'lds_f64', 'lds_u16', 'lds_f64x2', 'sunlit',
+    'nxc_device.hpp': ['lut_interp', 'lut_cell', 'lut_probe_cell', 'lut_probe_rows', 'lut_probe', 'lut_finish', 'lds_f64', 'lds_u16', 'lds_f64x2', 'sunlit',
                        'state_eval', 'rk5_step', 'apply_fate', 'bin_index', 'image_locate',
                        'image_weight', 'image_sample', 'image_add_pairs', 'push', 'pop', 'waiting',
                        'image_regs', 'wave_uniform', 'nxc_div_const', 'half_swap',
