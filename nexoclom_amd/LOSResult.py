@@ -1,11 +1,17 @@
 """LOSResult: modelled radiance along spacecraft lines of sight, accumulated on the GPU.
 
-Mirrors data_simulation/LOSResult.py:19-105,202-276 and compute_iteration.py:90-240 of the
-reference for the path from catalogued Outputs to ``radiance`` / ``npackets`` per spectrum.  The
+Drop-in for data_simulation/LOSResult.py:19-105,202-276 and compute_iteration.py:90-240 of the
+reference on the path from catalogued Outputs to ``radiance`` / ``npackets`` per spectrum.  The
 reference takes a ``MESSENGERdata`` object (external package, unavailable); anything with the same
 duck type works here: ``.data`` (DataFrame with x, y, z, xbore, ybore, zbore in planet radii, model
 frame), ``.species``, ``.query``, ``.set_frame()``, ``len()``.  ``SpacecraftData`` is a minimal one
-for synthetic geometries.  The fitted-result machinery (LOSResultFitted, source maps, masks,
+for synthetic geometries.
+
+Division of labour: everything per SPECTRUM that involves libm trigonometry -- the planet cut-off,
+the geometric ladder of pre-selection spheres along the line of sight, the cone-angle threshold --
+is set up here with NumPy (``los_geometry``, ``arccos_threshold``), so that the thresholds are the
+reference's own doubles; every (sample, spectrum) pair test runs in the HIP kernel
+(``nxc_los_accumulate``).  The fitted-result machinery (LOSResultFitted, source maps, masks,
 PostgreSQL caching of iterations) is out of scope.
 """
 import numpy as np
@@ -13,16 +19,17 @@ import pandas as pd
 
 from .ModelImage import ModelResult
 
+POSITION = ('x', 'y', 'z')
+BORESIGHT = ('xbore', 'ybore', 'zbore')
+
 
 class SpacecraftData:
     """Minimal stand-in for MESSENGERuvvs.MESSENGERdata: positions and boresights per spectrum."""
 
     def __init__(self, x, y, z, xbore, ybore, zbore, species='Na', query='synthetic'):
-        self.data = pd.DataFrame({'x': x, 'y': y, 'z': z, 'xbore': xbore, 'ybore': ybore,
-                                  'zbore': zbore}, dtype=float)
-        self.species = species
-        self.query = query
-        self.frame = 'Model'
+        columns = dict(zip(POSITION + BORESIGHT, (x, y, z, xbore, ybore, zbore)))
+        self.data = pd.DataFrame(columns, dtype=float)
+        self.species, self.query, self.frame = species, query, 'Model'
 
     def set_frame(self, frame):
         self.frame = frame
@@ -35,71 +42,72 @@ def arccos_threshold(dphi):
     """Smallest double c with arccos(c) <= dphi: the reference's ``ang <= dphi`` with
     ``ang = np.arccos(cosang)`` (compute_iteration.py:181-185) is then exactly ``cosang >= c`` for
     this NumPy's (monotone) arccos, so the kernel needs no arccos."""
-    lo, hi = 0.0, 1.0
-    assert np.arccos(lo) > dphi >= np.arccos(hi)
+    below, reached = 0.0, 1.0                # arccos(below) > dphi >= arccos(reached)
+    assert np.arccos(below) > dphi >= np.arccos(reached)
     while True:
-        mid = 0.5*(lo + hi)
-        if mid == lo or mid == hi:
-            break
-        if np.arccos(mid) <= dphi:
-            hi = mid
+        middle = 0.5*(below + reached)
+        if middle in (below, reached):
+            return reached
+        if np.arccos(middle) <= dphi:
+            reached = middle
         else:
-            lo = mid
-    return hi
+            below = middle
+
+
+def ladder_to(limit, first, ratio):
+    """t_0 = first, t_{k+1} = t_k + t_k * ratio, up to and including the first rung >= limit
+    (compute_iteration.py:164-167: sample points spaced in proportion to their distance)."""
+    rungs = [first]
+    while rungs[-1] < limit:
+        rungs.append(rungs[-1] + rungs[-1] * ratio)
+    return rungs
 
 
 def los_geometry(data, outeredge, dphi):
-    """Per-spectrum set-up of compute_iteration.py:101-115,157-167: planet cut-off distance (1e30
-    when the line of sight misses the planet) and the ladder t_k = t_{k-1}(1 + sin dphi) out to
-    the far side of the outer edge.  Returns (dist_from_plan, ladder lengths, longest ladder)."""
-    x, y, z = (data[k].values.astype(float) for k in ('x', 'y', 'z'))
-    xb, yb, zb = (data[k].values.astype(float) for k in ('xbore', 'ybore', 'zbore'))
+    """Per-spectrum set-up of compute_iteration.py:101-115,157-167.  Returns
+    (dist_from_plan, ladder lengths, longest ladder): the distance at which a line of sight that
+    hits the planet is cut (1e30 when it misses), and the ladder out to where the line leaves the
+    sphere r = outeredge -- all spectra share one geometric ladder, they differ in its length."""
+    at = data[list(POSITION)].values.astype(float)
+    look = data[list(BORESIGHT)].values.astype(float)
+    x, y, z = at.T
+    xb, yb, zb = look.T
     dist_from_plan = np.sqrt(x**2 + y**2 + z**2)
     with np.errstate(invalid='ignore'):
-        ang = np.arccos((-x*xb - y*yb - z*zb) / dist_from_plan)
-        asize_plan = np.arcsin(1. / dist_from_plan)
-    dist_from_plan = dist_from_plan.copy()
-    dist_from_plan[ang > asize_plan] = 1e30
-    lengths = np.zeros(len(x), dtype=np.int64)
-    longest = np.array([np.sin(dphi)])
-    for i in range(len(x)):
-        x_sc = np.array([x[i], y[i], z[i]])
-        bore = np.array([xb[i], yb[i], zb[i]])
+        off_centre = np.arccos((-x*xb - y*yb - z*zb) / dist_from_plan)
+        planet_size = np.arcsin(1. / dist_from_plan)
+    dist_from_plan = np.where(off_centre > planet_size, 1e30, dist_from_plan)
+    step = np.sin(dphi)
+    ladders = []
+    for x_sc, bore in zip(at, look):
+        # far root of |x_sc + t bore| = outeredge
         b = 2*np.sum(x_sc*bore)
         c = np.linalg.norm(x_sc)**2 - outeredge**2
         with np.errstate(invalid='ignore'):
-            dd = (-b + np.sqrt(b**2 - 4*1*c))/2
-        t = [np.sin(dphi)]
-        while t[-1] < dd:
-            t.append(t[-1] + t[-1] * np.sin(dphi))
-        lengths[i] = len(t)
-        if len(t) > len(longest):
-            longest = np.array(t)
-    return dist_from_plan, lengths, longest
+            far = (-b + np.sqrt(b**2 - 4*1*c))/2
+        ladders.append(ladder_to(far, step, step))
+    lengths = np.array([len(t) for t in ladders], dtype=np.int64)
+    return dist_from_plan, lengths, np.array(max(ladders, key=len))
 
 
 class LOSResult(ModelResult):
     def __init__(self, scdata, inputs, params=None, dphi=np.radians(1.), *, device=0,
                  context=None, **kwargs):
-        if params is None:
-            params = {'quantity': 'radiance'}
         scdata.set_frame('Model')
-        super().__init__(inputs, params)
+        super().__init__(inputs, {'quantity': 'radiance'} if params is None else params)
         if self.quantity != 'radiance':
             assert False, 'Other quantities not set up.'      # compute_iteration.py:213
-        self.species = scdata.species
-        self.query = scdata.query
         self.type = 'LineOfSight'
+        self.species, self.query = scdata.species, scdata.query
         self.dphi = float(dphi)
         self._oedge = np.min([self.inputs.options.outeredge*2, 100])
         self.fitted = self.inputs.options.fitted
-        nspec = len(scdata)
-        self.radiance = pd.Series(np.zeros(nspec), index=scdata.data.index)
-        self.npackets_los = pd.Series(np.zeros(nspec, dtype=np.int64), index=scdata.data.index)
+        rows = scdata.data.index
+        self.radiance = pd.Series(np.zeros(len(rows)), index=rows)
+        self.npackets_los = pd.Series(np.zeros(len(rows), dtype=np.int64), index=rows)
         self.included = None
         self.label = kwargs.get('label', 'LOSResult')
-        self._ctx = context
-        self._device = device
+        self._ctx, self._device = context, device
         self.iterations = []
 
     def context(self):
@@ -112,27 +120,25 @@ class LOSResult(ModelResult):
         """One catalogued Output against all spectra (compute_iteration.py:90-240)."""
         from .Output import Output
         output = Output.restore(output)
-        packets = output.X
-        data = scdata.data
-        outeredge = self.inputs.options.outeredge
-        dist_from_plan, lengths, ladder = los_geometry(data, outeredge, self.dphi)
-        sc = np.stack([data.x.values, data.y.values, data.z.values, data.xbore.values,
-                       data.ybore.values, data.zbore.values, dist_from_plan,
-                       lengths.astype(float)]).astype(float)
-        index = (packets['Index'].values if 'Index' in packets.columns
-                 else np.arange(len(packets)))
+        samples, spectra = output.X, scdata.data
+        cut, lengths, ladder = los_geometry(spectra, self.inputs.options.outeredge, self.dphi)
+        sc = np.vstack([spectra[list(POSITION + BORESIGHT)].values.T.astype(float), cut,
+                        lengths.astype(float)])
+        if 'Index' in samples.columns:
+            index = samples['Index'].values
+        else:
+            index = np.arange(len(samples))
         n_index = int(len(output.X0)) if len(output.X0) else int(index.max()) + 1
-        vr = float(output.vrplanet)/self.unit_km
         res = self.context().los_accumulate(
-            self.dphi, np.sin(self.dphi), np.sin(self.dphi*2), arccos_threshold(self.dphi), vr,
-            self.unit_km*1e5, self.g_tables(float(output.aplanet)), ladder, sc,
-            packets['x'].values, packets['y'].values, packets['z'].values, packets['vy'].values,
-            packets['frac'].values, index=index, n_index=n_index, used_cap=used_cap)
-        ctr = self.context().counters()
-        assert ctr['nonfinite'] == 0, 'Non-finite weights'
+            self.dphi, np.sin(self.dphi), np.sin(self.dphi*2), arccos_threshold(self.dphi),
+            float(output.vrplanet)/self.unit_km, self.unit_km*1e5,
+            self.g_tables(float(output.aplanet)), ladder, sc,
+            *(samples[c].values for c in ('x', 'y', 'z', 'vy', 'frac')),
+            index=index, n_index=n_index, used_cap=used_cap)
+        assert self.context().counters()['nonfinite'] == 0, 'Non-finite weights'
         res['totalsource'] = output.totalsource
-        res['radiance'] = pd.Series(res['radiance'], index=data.index)
-        res['npackets'] = pd.Series(res['npackets'], index=data.index)
+        for key in ('radiance', 'npackets'):
+            res[key] = pd.Series(res[key], index=spectra.index)
         return res
 
     def simulate_data_from_inputs(self, scdata, distribute=None):
@@ -144,13 +150,11 @@ class LOSResult(ModelResult):
         print(f'LOSResult: {len(self.outid)} output files found.')
         if self.npackets == 0:
             raise RuntimeError('No packets found for these Inputs.')
-        self.iterations = []
-        for out in self.inputs._catalogue:
-            it = self.compute_iteration(out, scdata)
+        self.iterations = [self.compute_iteration(run, scdata) for run in self.inputs._catalogue]
+        for it in self.iterations:
             assert len(it['radiance']) == len(scdata.data)
-            self.iterations.append(it)
             self.radiance += it['radiance']
             self.npackets_los += it['npackets']
-        model_rate = self.totalsource / self.inputs.options.endtime.value
-        self.atoms_per_packet = 1e23 / model_rate
+        per_second = self.totalsource / self.inputs.options.endtime.value
+        self.atoms_per_packet = 1e23 / per_second
         self.radiance *= self.atoms_per_packet/1e3      # kR

@@ -13,7 +13,8 @@ Two ways to get the packets:
 * STREAMING (keyword ``npackets``): integrate and bin in one persistent kernel; the trajectory
   tensor is never built.  ``downcast=True`` (default) applies the reference's float32
   save/restore rounding to every sample before binning, so the image is the one the reference's
-  two-stage pipeline produces.
+  two-stage pipeline produces.  ``shard=(lo, hi)`` restricts the run to those global packet
+  indices (multi-GPU, nexoclom_amd.distributed).
 
 Bokeh display / PostgreSQL caching of the reference are out of scope.
 """
@@ -27,15 +28,45 @@ from .atomicdata import gValue
 from .input_classes import InputError
 from .units import Quantity
 
+QUANTITIES = ('column', 'radiance', 'density', 'difrad')
+EMISSION = ('radiance', 'difrad')
+# resonance lines [Angstrom] summed when params name none (ModelResult.py:124-129)
+DEFAULT_LINES = {'Na': (5891, 5897), 'Ca': (4227,), 'Mg': (2852,)}
+
 
 def rotation_matrix(theta, axis):
-    """Rotation by theta about axis (math/rotation_matrix.py:5-14)."""
+    """Rotation by theta about axis, element for element math/rotation_matrix.py:5-14 (the image
+    must bin with the same 3 x 3 doubles as the reference)."""
     u = axis/np.linalg.norm(axis)
     lx, ly, lz = u[0], u[1], u[2]
     c, s = np.cos(theta), np.sin(theta)
     return np.array([[lx**2+(1-lx**2)*c, lx*ly*(1-c)+lz*s, lx*lz*(1-c)-ly*s],
                      [lx*ly*(1-c)-lz*s, ly**2+(1-ly**2)*c, ly*lz*(1-c)+lx*s],
                      [lx*lz*(1-c)+ly*s, ly*lz*(1-c)-lx*s, lz**2+(1-lz**2)*c]])
+
+
+def read_params(params):
+    """The format description of a model result: a dict as given, or the ``key = value`` lines of
+    a file (``;`` / ``#`` comments, keys lower-cased; ModelResult.py:77-101)."""
+    if isinstance(params, dict):
+        return params
+    if not isinstance(params, str):
+        raise TypeError('ModelResult.__init__', 'params must be a dict or filename.')
+    if not os.path.exists(params):
+        raise FileNotFoundError('ModelResult.__init__', 'params file not found.')
+    table = {}
+    with open(params, 'r') as handle:
+        for raw in handle:
+            text = raw.split(';' if ';' in raw else '#', 1)[0]
+            key, eq, value = text.partition('=')
+            if eq:
+                table[key.strip().lower()] = value.strip()
+    return table
+
+
+def _two(text, convert):
+    first, second = str(text).split(',')[:2]
+    return [convert(first), convert(second)]
 
 
 class Histogram2dResult:
@@ -49,6 +80,9 @@ class Histogram2dResult:
 
 
 class ModelResult:
+    """What an image and a line-of-sight result share: the parsed ``params``, the observed
+    quantity and, for emission, which lines' g-values weight the packets."""
+
     def __init__(self, inputs, params):
         self.inputs = copy.copy(inputs)
         self.outid, self.outputfiles, _, _ = inputs.search()
@@ -56,68 +90,40 @@ class ModelResult:
         self.totalsource = 0.
         self.atoms_per_packet = 0.
         self.sourcerate = Quantity(0., '1e23/s')
-        if isinstance(params, str):
-            if os.path.exists(params):
-                self.params = {}
-                with open(params, 'r') as f:
-                    for line in f:
-                        if ';' in line:
-                            line = line[:line.find(';')]
-                        elif '#' in line:
-                            line = line[:line.find('#')]
-                        if '=' in line:
-                            p, v = line.split('=')
-                            self.params[p.strip().lower()] = v.strip()
-            else:
-                raise FileNotFoundError('ModelResult.__init__', 'params file not found.')
-        elif isinstance(params, dict):
-            self.params = params
-        else:
-            raise TypeError('ModelResult.__init__', 'params must be a dict or filename.')
-
-        quantities = ('column', 'radiance', 'density', 'difrad')
-        self.quantity = self.params.get('quantity', None)
-        if (self.quantity is None) or (self.quantity not in quantities):
+        self.params = read_params(params)
+        self.quantity = self.params.get('quantity')
+        if self.quantity not in QUANTITIES:
             raise InputError('ModelImage.__init__', "quantity must be 'column' or 'radiance'")
         self.g = self.params.get('g', None)
-
-        if self.quantity in ('radiance', 'difrad'):
-            self.mechanism = ['resonant scattering']
-            species = inputs.options.species
-            if 'wavelength' in self.params:
-                self.wavelength = tuple(sorted(int(m.strip()) for m
-                                               in str(self.params['wavelength']).split(',')))
-            elif species is None:
-                raise InputError('ModelImage.__init__',
-                                 'Must provide either species or params.wavelength')
-            elif species == 'Na':
-                self.wavelength = (5891, 5897)
-            elif species == 'Ca':
-                self.wavelength = (4227,)
-            elif species == 'Mg':
-                self.wavelength = (2852,)
-            else:
-                raise InputError('ModelResult.__init__',
-                                 f'Default wavelengths not available for {species}')
-        else:
-            self.mechanism = None
-            self.wavelength = None
+        emits = self.quantity in EMISSION
+        self.mechanism = ['resonant scattering'] if emits else None
+        self.wavelength = self._lines(inputs.options.species) if emits else None
         self.unit = 'R_' + inputs.geometry.planet.object
         self.unit_km = inputs.geometry.planet.radius.value
 
+    def _lines(self, species):
+        if 'wavelength' in self.params:
+            return tuple(sorted(int(w.strip()) for w in str(self.params['wavelength']).split(',')))
+        if species is None:
+            raise InputError('ModelImage.__init__',
+                             'Must provide either species or params.wavelength')
+        if species not in DEFAULT_LINES:
+            raise InputError('ModelResult.__init__',
+                             f'Default wavelengths not available for {species}')
+        return DEFAULT_LINES[species]
+
     def g_tables(self, aplanet):
         """[(velocity [R/s], g [1/s])] per emission line (ModelResult.py:152-157: gValue tables
-        with the velocity axis converted to the packets' unit)."""
-        if self.quantity not in ('radiance', 'difrad'):
+        with the velocity axis converted to the packets' unit); a constant ``g`` in params is a
+        flat two-point table, which makes every packet's g that constant."""
+        if self.quantity not in EMISSION:
             return []
         if self.g is not None:
-            # constant g: a flat two-point table reproduces gg = g for every packet
-            return [(np.array([-1e30, 1e30]), np.array([float(self.g), float(self.g)]))]
-        tables = []
-        for w in self.wavelength:
-            gval = gValue(self.inputs.options.species, w, aplanet)
-            tables.append((gval.velocity/self.unit_km, gval.g))
-        return tables
+            flat = float(self.g)
+            return [(np.array([-1e30, 1e30]), np.array([flat, flat]))]
+        species = self.inputs.options.species
+        lines = (gValue(species, w, aplanet) for w in self.wavelength)
+        return [(line.velocity/self.unit_km, line.g) for line in lines]
 
 
 class ModelImage(ModelResult):
@@ -130,62 +136,62 @@ class ModelImage(ModelResult):
         if self.origin != inputs.geometry.planet:
             raise NotImplementedError('images centred on another object '
                                       '(ModelResult.transform_reference_frame) are out of scope')
-
-        dimtemp = str(self.params.get('dims', '800,800')).split(',')
-        self.dims = [int(dimtemp[0]), int(dimtemp[1])]
-        centtemp = str(self.params.get('center', '0,0')).split(',')
-        self.center = [Quantity(float(centtemp[0]), self.unit),
-                       Quantity(float(centtemp[1]), self.unit)]
-        widtemp = str(self.params.get('width', '8,8')).split(',')
-        self.width = [Quantity(float(widtemp[0]), self.unit),
-                      Quantity(float(widtemp[1]), self.unit)]
-        self.subobslongitude = Quantity(float(self.params.get('subobslongitude', '0')), 'rad')
-        self.subobslatitude = Quantity(float(self.params.get('subobslatitude', np.pi/2)), 'rad')
-
+        self._frame()
         self.image = np.zeros(self.dims)
         self.packet_image = np.zeros(self.dims)
         self.blimits = None
-        immin = tuple(c - w/2 for c, w in zip(self.center, self.width))
-        immax = tuple(c + w/2 for c, w in zip(self.center, self.width))
-        self.xrange = [immin[0], immax[0]]
-        self.zrange = [immin[1], immax[1]]
-        scale = tuple(w/d for w, d in zip(self.width, self.dims))
-        R_cm = self.unit_km*1e5
-        self.Apix = Quantity(scale[0]*scale[1]*R_cm**2, 'cm2')       # ModelImage.py:77-78
-        self.xedges = np.linspace(self.xrange[0], self.xrange[1], self.dims[0]+1)
-        self.zedges = np.linspace(self.zrange[0], self.zrange[1], self.dims[1]+1)
         self.xaxis = None
         self.zaxis = None
         self._ctx = context
         self._device = device
         self.counters = {}
-
         if npackets is not None:
-            lo, hi = (0, int(npackets)) if shard is None else (int(shard[0]), int(shard[1]))
-            if not 0 <= lo <= hi <= int(npackets):
+            total = int(npackets)
+            lo, hi = (0, total) if shard is None else (int(shard[0]), int(shard[1]))
+            if not 0 <= lo <= hi <= total:
                 raise ValueError('shard must be an index range inside [0, npackets]')
-            self._stream(int(npackets), seed, packs_per_it, downcast, sampler, lo, hi)
+            self._stream(total, seed, packs_per_it, downcast, sampler, lo, hi)
         else:
-            outputs = [o for o in inputs._catalogue]
-            if not outputs:
-                print('No model outputs found for these inputs.')
-            for out in outputs:
-                print(f'Output filename: {out.filename}')
-                image, packets = self.create_image(out)
-                self.image += image.histogram
-                self.packet_image += packets.histogram
-                self.totalsource += out.totalsource
-                self.xaxis = image.x
-                self.zaxis = image.y
-
+            self._from_catalogue()
         if finalize:
             self.finalize()
+
+    def _frame(self):
+        """Image plane from params (ModelImage.py:53-78): dims (default 800 x 800), center and
+        width in planet radii (0,0 and 8 x 8), the sub-observer point (longitude 0, latitude
+        pi/2: looking down on the north pole), the bin edges and the pixel area in cm^2."""
+        get = self.params.get
+        length = lambda text: Quantity(float(text), self.unit)          # noqa: E731
+        self.dims = _two(get('dims', '800,800'), int)
+        self.center = _two(get('center', '0,0'), length)
+        self.width = _two(get('width', '8,8'), length)
+        self.subobslongitude = Quantity(float(get('subobslongitude', '0')), 'rad')
+        self.subobslatitude = Quantity(float(get('subobslatitude', np.pi/2)), 'rad')
+        self.xrange, self.zrange = ([c - w/2, c + w/2] for c, w in zip(self.center, self.width))
+        pixel = [w/d for w, d in zip(self.width, self.dims)]
+        R_cm = self.unit_km*1e5
+        self.Apix = Quantity(pixel[0]*pixel[1]*R_cm**2, 'cm2')
+        self.xedges = np.linspace(self.xrange[0], self.xrange[1], self.dims[0]+1)
+        self.zedges = np.linspace(self.zrange[0], self.zrange[1], self.dims[1]+1)
+
+    def _from_catalogue(self):
+        """Sum of the images of every catalogued Output (ModelImage.py:85-98)."""
+        runs = list(self.inputs._catalogue)
+        if not runs:
+            print('No model outputs found for these inputs.')
+        for run in runs:
+            print(f'Output filename: {run.filename}')
+            weighted, counted = self.create_image(run)
+            self.image += weighted.histogram
+            self.packet_image += counted.histogram
+            self.totalsource += run.totalsource
+            self.xaxis, self.zaxis = weighted.x, weighted.y
 
     def finalize(self):
         """Scale to a source rate of 1e23 atoms/s (ModelImage.py:102-105); deferred by the
         multi-GPU path until the shards are summed."""
-        mod_rate = self.totalsource / self.inputs.options.endtime.value
-        self.atoms_per_packet = 1e23 / mod_rate if mod_rate > 0 else 0.
+        per_second = self.totalsource / self.inputs.options.endtime.value
+        self.atoms_per_packet = 1e23 / per_second if per_second > 0 else 0.
         self.sourcerate = Quantity(1., '1e23/s')
         self.image *= self.atoms_per_packet
 
@@ -197,15 +203,15 @@ class ModelImage(ModelResult):
         return self._ctx
 
     def image_rotation(self):
-        """ModelImage.py:367-384."""
-        slong, slat = float(self.subobslongitude), float(self.subobslatitude)
-        pSun = np.array([0., -1., 0.])
-        pObs = np.array([np.sin(slong)*np.cos(slat), -np.cos(slong)*np.cos(slat), np.sin(slat)])
-        if np.array_equal(pSun, pObs):
+        """Sun frame -> observer frame (ModelImage.py:367-384): the rotation that carries the
+        sub-solar direction (0,-1,0) onto the sub-observer direction."""
+        lon, lat = float(self.subobslongitude), float(self.subobslatitude)
+        sun = np.array([0., -1., 0.])
+        observer = np.array([np.sin(lon)*np.cos(lat), -np.cos(lon)*np.cos(lat), np.sin(lat)])
+        if np.array_equal(sun, observer):
             return np.eye(3)
-        costh = np.dot(pSun, pObs)/np.linalg.norm(pSun)/np.linalg.norm(pObs)
-        theta = np.arccos(np.clip(costh, -1, 1))
-        return rotation_matrix(theta, np.cross(pSun, pObs))
+        cosine = np.dot(sun, observer)/np.linalg.norm(sun)/np.linalg.norm(observer)
+        return rotation_matrix(np.arccos(np.clip(cosine, -1, 1)), np.cross(sun, observer))
 
     def _set_image(self, ctx, aplanet, vrplanet_Rs, downcast):
         ctx.set_image(self.image_rotation(), vrplanet_Rs, float(self.Apix), self.quantity,
@@ -216,15 +222,14 @@ class ModelImage(ModelResult):
         weight and histogram -- the last four inside one HIP kernel."""
         from .Output import Output
         output = Output.restore(output)
-        packets = output.X
-        if len(packets) == 0 or 'x' not in packets:
+        rows = output.X
+        if len(rows) == 0 or 'x' not in rows:
             raise ValueError('this Output holds no trajectory (it was run with '
                              'keep_trajectory=False); use ModelImage(..., npackets=N) instead')
         ctx = self.context()
         vr = float(output.vrplanet)/self.unit_km          # km/s -> R/s (ModelImage.py:242-243)
         self._set_image(ctx, float(output.aplanet), vr, downcast=False)
-        ctx.image_accumulate(packets['x'].values, packets['y'].values, packets['z'].values,
-                             packets['vy'].values, packets['frac'].values)
+        ctx.image_accumulate(*(rows[c].values for c in ('x', 'y', 'z', 'vy', 'frac')))
         self.counters = ctx.counters()
         assert self.counters['nonfinite'] == 0, 'Non-finite weights'
         image, counts = ctx.image_download()
@@ -295,9 +300,7 @@ class ModelImage(ModelResult):
         self.xaxis, self.zaxis = h.x, h.y
 
     def export(self, filename='image.json'):
-        if filename.endswith('.json'):
-            with open(filename, 'w') as f:
-                json.dump({'image': self.image.tolist(), 'xaxis': self.xaxis.tolist(),
-                           'zaxis': self.zaxis.tolist()}, f)
-        else:
+        if not filename.endswith('.json'):
             raise TypeError('Not an valid file format')
+        with open(filename, 'w') as handle:
+            json.dump({k: getattr(self, k).tolist() for k in ('image', 'xaxis', 'zaxis')}, handle)

@@ -1,84 +1,84 @@
 """Surface interaction set-up for re-emitted packets (host side).
 
-Re-statement of initial_state/surface_temperature.py:4-19 and
-particle_tracking/SurfaceInteraction.py:10-61 of the reference: the Mercury surface temperature
-model, the temperature-dependent sticking coefficient, and the table of thermally accommodated
-emission speeds v(T, probability) with its interpolating bicubic spline (scipy
-RectBivariateSpline = FITPACK).  ``bounce_tables()`` exports the spline's knots and coefficients so
-that the HIP kernel evaluates the same spline (de Boor) at every impact.
+What the kernels need when a packet that hits the surface is not simply absorbed
+(particle_tracking/bouncepackets.py:39-100): the Mercury surface-temperature model
+(initial_state/surface_temperature.py:4-19), the temperature-dependent sticking coefficient and
+the table of thermally accommodated emission speeds v(T, probability) with its interpolating
+bicubic spline (particle_tracking/SurfaceInteraction.py:10-61: scipy RectBivariateSpline =
+FITPACK).  ``bounce_tables()`` exports the spline's knots and coefficients so that the HIP kernel
+evaluates the very same spline (de Boor) at every impact.
 """
 import numpy as np
 from scipy import interpolate
 
 from . import constants as const
-from .source_distribution import MaxwellianDist
+from .source_distribution import MaxwellianDist, density_cdf
 
-
-def surface_temperature(geometry, longitude, latitude, t0=100., t1=None, n=.25):
-    """surface_temperature.py:4-19 (Mercury only): t0 on the night side,
-    t0 + t1 |cos(lon) cos(lat)|^n on the day side, t1 = 600 + 125 (cos(taa) - 1)/2."""
-    if geometry.startpoint != 'Mercury':
-        raise NotImplementedError('surface temperature is only defined for Mercury')
-    if t1 is None:
-        t1 = 600. + 125*(np.cos(float(geometry.taa)) - 1)/2.
-    longitude = np.asarray(longitude, dtype=float)
-    latitude = np.asarray(latitude, dtype=float)
-    t_surf = np.zeros_like(longitude) + t0
-    mask = (longitude <= np.pi/2) | (longitude >= 3*np.pi/2)
-    t_surf[mask] = t0 + t1*np.abs(np.cos(longitude[mask]) * np.cos(latitude[mask]))**n
-    return t_surf
+NIGHT_SIDE_K = 100.
 
 
 def day_side_t1(geometry):
+    """Sub-solar excess temperature [K] at the planet's true anomaly."""
     return 600. + 125*(np.cos(float(geometry.taa)) - 1)/2.
+
+
+def surface_temperature(geometry, longitude, latitude, t0=NIGHT_SIDE_K, t1=None, n=.25):
+    """Mercury only (surface_temperature.py:4-19): t0 on the night side; on the day side (within
+    90 degrees of the sub-solar longitude) t0 + t1 |cos(lon) cos(lat)|^n."""
+    if geometry.startpoint != 'Mercury':
+        raise NotImplementedError('surface temperature is only defined for Mercury')
+    excess = day_side_t1(geometry) if t1 is None else t1
+    lon = np.asarray(longitude, dtype=float)
+    lat = np.asarray(latitude, dtype=float)
+    day = (lon <= np.pi/2) | (lon >= 3*np.pi/2)
+    temperature = np.full_like(lon, t0)
+    temperature[day] = t0 + excess*np.abs(np.cos(lon[day]) * np.cos(lat[day]))**n
+    return temperature
 
 
 class SurfaceInteraction:
     """SurfaceInteraction.py:10-61: ``stickcoef(lon, lat)`` for temperature-dependent sticking
-    and ``v_interp(T, p)`` [km/s] for accommodation (when accomfactor != 0)."""
+    and ``v_interp(T, p)`` [km/s] for accommodation (when accomfactor != 0): the speed below which
+    a fraction p of a Maxwellian flux at temperature T is emitted, tabulated on ``nt``
+    temperatures spanning the planet's surface and ``nprob`` probabilities."""
 
     def __init__(self, inputs, nt=201, nv=101, nprob=101):
-        sint = inputs.surfaceinteraction
+        spec = inputs.surfaceinteraction
         self.inputs = inputs
-        if sint.sticktype == 'temperature dependent':
-            A = sint.A
-
-            def stickcoef(lon, lat):
-                tsurf = surface_temperature(inputs.geometry, lon, lat)
-                coef = A[0] * np.exp(A[1]*tsurf) + A[2]
-                coef[coef > 1.] = 1.
-                coef[coef < 0.] = 0.
-                return coef
-            self.stickcoef = stickcoef
-        elif sint.sticktype == 'surface map':
-            assert 0
+        assert spec.sticktype != 'surface map', 'sticking maps are out of scope'
+        if spec.sticktype == 'temperature dependent':
+            self.stickcoef = self._sticking_law(inputs.geometry, spec.A)
         self.spline = None
-        if sint.accomfactor != 0:
-            longitude = np.arange(361)*np.pi/180.
-            latitude = np.arange(181)*np.pi/180. - np.pi/2.
-            longrid, latgrid = np.meshgrid(longitude, latitude)
-            tsurf = surface_temperature(inputs.geometry, longrid.flatten(), latgrid.flatten())
-            temperature = np.linspace(min(tsurf), max(tsurf), nt)
-            mass = const.ATOMIC_MASS[inputs.options.species]*const.AMU
-            v_temp = np.sqrt(2*temperature*const.K_B/mass)/1e3            # km/s
-            probability = np.linspace(0, 1, nprob)
-            probgrid = np.ndarray((nt, nprob))
-            for i, t in enumerate(temperature):
-                vrange = np.linspace(0, v_temp[i]*3, nv)
-                f_v = MaxwellianDist(vrange, t, inputs.options.species)
-                cumdist = f_v.cumsum()
-                cumdist -= cumdist.min()
-                cumdist /= cumdist.max()
-                probgrid[i, :] = np.interp(probability, cumdist, vrange)
-            self.spline = interpolate.RectBivariateSpline(temperature, probability, probgrid)
-            self.v_interp = self.spline.ev
-            self.probgrid = probgrid
-            self.temperature = temperature
-            self.probability = probability
+        if spec.accomfactor != 0:
+            self._tabulate(inputs, nt, nv, nprob)
+
+    @staticmethod
+    def _sticking_law(geometry, A):
+        def stickcoef(lon, lat):
+            warm = surface_temperature(geometry, lon, lat)
+            return np.clip(A[0] * np.exp(A[1]*warm) + A[2], 0., 1.)
+        return stickcoef
+
+    def _tabulate(self, inputs, nt, nv, nprob):
+        species = inputs.options.species
+        lon, lat = np.meshgrid(np.arange(361)*np.pi/180., np.arange(181)*np.pi/180. - np.pi/2.)
+        everywhere = surface_temperature(inputs.geometry, lon.flatten(), lat.flatten())
+        self.temperature = np.linspace(min(everywhere), max(everywhere), nt)
+        self.probability = np.linspace(0, 1, nprob)
+        mass = const.ATOMIC_MASS[species]*const.AMU
+        thermal = np.sqrt(2*self.temperature*const.K_B/mass)/1e3            # km/s
+        self.probgrid = np.ndarray((nt, nprob))
+        for row, (kelvin, v_th) in enumerate(zip(self.temperature, thermal)):
+            speeds = np.linspace(0, v_th*3, nv)
+            cdf, grid = density_cdf(speeds, MaxwellianDist(speeds, kelvin, species))
+            self.probgrid[row, :] = np.interp(self.probability, cdf, grid)
+        self.spline = interpolate.RectBivariateSpline(self.temperature, self.probability,
+                                                      self.probgrid)
+        self.v_interp = self.spline.ev
 
     def bounce_tables(self):
-        """(tx, ty, coef[nx-4, ny-4]) of the bicubic spline, or three one-element dummies when
-        there is no accommodation."""
+        """(tx, ty, coef[nx-4, ny-4]) of the bicubic spline, or zero-filled dummies when there is
+        no accommodation."""
         if self.spline is None:
             return np.zeros(8), np.zeros(8), np.zeros((4, 4))
         tx, ty, c = self.spline.tck
@@ -87,20 +87,19 @@ class SurfaceInteraction:
 
 
 def bounce_config(inputs, GM, unit_km, seed):
-    """Everything the kernels need to re-emit a packet that hit the surface
-    (particle_tracking/bouncepackets.py:39-100), as keyword arguments of
-    hip_api.Context.set_bounce; None when packets simply stick (stickcoef == 1)."""
-    sint = inputs.surfaceinteraction
-    if sint.sticktype == 'constant' and sint.stickcoef == 1.:
+    """Keyword arguments of hip_api.Context.set_bounce for these inputs; None when packets simply
+    stick (stickcoef == 1)."""
+    spec = inputs.surfaceinteraction
+    if spec.sticktype == 'constant' and spec.stickcoef == 1.:
         return None
     surf = SurfaceInteraction(inputs)
     tx, ty, coef = surf.bounce_tables()
-    tdep = sint.sticktype == 'temperature dependent'
+    by_temperature = spec.sticktype == 'temperature dependent'
     return dict(GM=float(GM), unit_km=float(unit_km),
-                accomfactor=float(sint.accomfactor or 0.0),
-                temp_dependent=int(tdep),
-                stickcoef=0.0 if tdep else float(sint.stickcoef),
-                A=tuple(sint.A) if tdep else (0., 0., 0.),
-                t0=100., t1=float(day_side_t1(inputs.geometry)), tpow=0.25,
+                accomfactor=float(spec.accomfactor or 0.0),
+                temp_dependent=int(by_temperature),
+                stickcoef=0.0 if by_temperature else float(spec.stickcoef),
+                A=tuple(spec.A) if by_temperature else (0., 0., 0.),
+                t0=NIGHT_SIDE_K, t1=float(day_side_t1(inputs.geometry)), tpow=0.25,
                 tx=tx, ty=ty, coef=coef, seed=0 if seed is None else int(seed),
                 surf=surf)

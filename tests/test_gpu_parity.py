@@ -263,3 +263,42 @@ def test_compact_rows_equal_the_filtered_dense_trajectory(ctx, coracle, bounce):
     if not bounce:
         c = coracle.integrate_const(f, X0, step, n_iter, 6.0, nrec=nsteps)
         assert np.array_equal(dense, c['traj'])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_lookup_table_equals_np_interp_on_adversarial_tables(ctx, seed):
+    """The LDS lookup (clamp-free cell index, host-bisected cell table, two-row probe, rare walk)
+    against np.interp itself, through nxc_state with gravity off (ay = interp(vy + vrplanet) for a
+    sunlit packet): tables with nodes clustered far below the cell width, two-point tables and a
+    Na-sized irregular one; abscissae at the nodes, one ulp either side of them, between them, at
+    and beyond both ends, huge, and NaN.  Bit-exact."""
+    rng = np.random.default_rng(seed)
+    n = [2, 40, 827, 1200][seed]
+    if seed == 1:                       # clusters: many nodes inside single cells
+        base = np.sort(rng.uniform(-1, 1, 8))
+        xp = np.unique(np.concatenate([base + k*1e-9 for k in range(5)]))
+    elif seed == 0:
+        xp = np.array([-0.37, 0.91])
+    else:
+        xp = np.unique(np.cumsum(rng.choice([1e-6, 3e-3, 1e-2, 0.2], size=n, p=[.05, .4, .4, .15])))
+        xp = xp - xp.mean()
+    fp = rng.normal(size=len(xp))
+    vr = 0.125
+    f = O.Forces(GM=-1.5e-6, vrplanet=vr, gravity=False, radpres=True, lifetime=0., photo=None,
+                 v_tab=xp, a_tab=fp)
+    H.set_ctx_forces(ctx, f)
+    span = xp[-1] - xp[0]
+    xs = np.concatenate([xp, np.nextafter(xp, np.inf), np.nextafter(xp, -np.inf),
+                         rng.uniform(xp[0] - 0.3*span, xp[-1] + 0.3*span, 200000),
+                         (xp[:-1] + xp[1:])/2, [xp[0] - 1e-300, xp[-1] + 1e300, -1e308, 1e308,
+                                                0.0, -0.0, np.nan]])
+    vy = xs - vr
+    keep = (vy + vr == xs) | np.isnan(xs)          # only abscissae the kernel reconstructs exactly
+    xs, vy = xs[keep], vy[keep]
+    m = len(xs)
+    # a sunlit position: y < 0
+    a, ion = ctx.state(np.zeros(m), -2*np.ones(m), np.zeros(m), vy)
+    want = np.interp(xs, xp, fp)
+    assert keep.sum() > 100000
+    assert np.array_equal(a[:, 1], want, equal_nan=True)
+    assert np.array_equal(a[:, 0], np.zeros(m)) and np.array_equal(ion, np.zeros(m))
