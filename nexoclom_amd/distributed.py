@@ -78,6 +78,8 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if n > (1 << 31):
+        raise ConnectionError('control-plane message of absurd length')
     return _recv_exact(sock, n)
 
 
@@ -130,15 +132,16 @@ class ControlPlane:
         try:
             while len(self._peers) < self.world - 1:
                 conn, _ = srv.accept()
-                conn.settimeout(self.timeout)
+                conn.settimeout(5.0)             # a stranger on the port must not stall the job
                 try:
                     hello = _recv(conn)
                     magic, tok, r = hello[:5], hello[5:37].decode(), struct.unpack('<I', hello[37:41])[0]
                     if magic != _MAGIC or tok != token or not 0 < r < self.world or r in self._peers:
                         raise ConnectionError('bad hello')
-                except (ConnectionError, OSError, struct.error, UnicodeDecodeError):
+                except (ConnectionError, OSError, struct.error, UnicodeDecodeError, MemoryError):
                     conn.close()
                     continue
+                conn.settimeout(self.timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 _send(conn, _MAGIC + token.encode())
                 self._peers[r] = conn

@@ -78,3 +78,31 @@ def test_package_does_not_import_the_oracle():
             if isinstance(node, (ast.Import, ast.ImportFrom)):
                 mod = getattr(node, 'module', '') or ''
                 assert 'oracle' not in mod and all('oracle' not in a.name for a in node.names), fn
+
+
+def test_ctypes_structs_match_the_compiled_header(tmp_path):
+    """Every struct of include/nexoclom_hip.h as gcc lays it out (sizeof and the offset of each
+    field) against the ctypes mirror in hip_api.py: a field added on one side only shows up here."""
+    import subprocess
+    import sys
+    structs = ['nxc_forces', 'nxc_image_desc', 'nxc_counters', 'nxc_bounce_desc',
+               'nxc_bodies_desc', 'nxc_source_desc', 'nxc_los_desc']
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void){']
+    for name in structs:
+        ct = getattr(hip_api, name)
+        lines.append(f'printf("{name} %zu", sizeof({name}));')
+        for field, *_ in ct._fields_:
+            lines.append(f'printf(" %zu", offsetof({name}, {field}));')
+        lines.append('printf("\\n");')
+    lines.append('return 0;}')
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).strip().splitlines()
+    assert len(out) == len(structs)
+    for row in out:
+        name, size, *offsets = row.split()
+        ct = getattr(hip_api, name)
+        assert int(size) == C.sizeof(ct), name
+        assert [int(o) for o in offsets] == [getattr(ct, f).offset for f, *_ in ct._fields_], name
