@@ -831,7 +831,7 @@ int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
     });
 }
 
-#ifdef NXC_EXPERIMENT_KNOBS
+#ifdef NXC_STAMPS
 extern "C" int nxc_debug_stamps(nxc_handle *h, unsigned long long out[8])
 {
     DevCounters c;

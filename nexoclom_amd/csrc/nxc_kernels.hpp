@@ -21,12 +21,12 @@
 struct DevCounters {
     unsigned long long particle_steps, samples, samples_binned, nonfinite, bad_step, neg_frac,
         unfinished, queue_head;
-#ifdef NXC_EXPERIMENT_KNOBS     // diagnostic build only: summed s_memtime shares of the loop segments
+#ifdef NXC_STAMPS               // diagnostic build only: summed s_memtime shares of the loop segments
     unsigned long long stamp[8];
 #endif
 };
 
-#ifdef NXC_EXPERIMENT_KNOBS
+#ifdef NXC_STAMPS
 // In-kernel stamp (cdna_hip_programming.md, "In-kernel stamps"): one asm statement, fenced by
 // scheduling barriers.  Diagnostic builds only; the product build has none.
 NXC_DEV unsigned long long nxc_stamp()
@@ -403,7 +403,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     // neither fresh nor free holds a live packet with k < n_iter.
     // Image: every trip locates its samples (rotation, bins, masks) and queues the ones inside
     // the image; whenever 64 are waiting they are weighted and added by a full wave.
-#ifdef NXC_EXPERIMENT_KNOBS
+#ifdef NXC_STAMPS
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = nxc_stamp();
 #endif
     for (;;) {
@@ -450,20 +450,31 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         }
         NXC_STAMP(3);                                  // final-state bookkeeping
         if (IMAGE) {                                  // wave-cooperative: outside `if (has)`
+#ifdef NXC_EXPERIMENT_KNOBS
+            // timing experiments (tools/gpu_exp_dbg.py): 3 = locate only, 2 = + queue, no weight,
+            // 1 = everything but the atomics
+            if (IR.dbg == 3) { my_binned += p >= 0; continue; }
+#endif
             queue.push(p >= 0, p, rv, fw, imgq_off);
             NXC_STAMP(4);                              // push
             if (queue.waiting() >= 64) {
                 double w = 0.0;
                 bool ok = queue.pop(imgq_off, p, rv, fw);
+#ifdef NXC_EXPERIMENT_KNOBS
+                if (IR.dbg == 2) { my_binned += ok; continue; }
+#endif
                 if (ok && !image_weight(lds_header().G, IR, rv, fw, w)) { my_nonfinite++; ok = false; }
                 my_binned += ok;
                 NXC_STAMP(5);                          // pop + weight
+#ifdef NXC_EXPERIMENT_KNOBS
+                if (IR.dbg == 1) { my_nonfinite += (w == 12345.678); continue; }
+#endif
                 image_add_pairs(ok, p, w, acc2);
                 NXC_STAMP(6);                          // atomics
             }
         }
     }
-#ifdef NXC_EXPERIMENT_KNOBS
+#ifdef NXC_STAMPS
     if ((threadIdx.x & 63) == 0)
         for (int c = 0; c < 8; c++) atomicAdd(&ctr->stamp[c], seg[c]);
 #endif

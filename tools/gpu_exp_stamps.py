@@ -1,5 +1,5 @@
 """Where a trip through the persistent loop spends its cycles: s_memtime shares per segment from a
-diagnostic build (hipcc ... -DNXC_EXPERIMENT_KNOBS -o variants/lib_stamps.so).  The stamps forbid
+diagnostic build (hipcc ... -DNXC_STAMPS -o variants/lib_stamps.so).  The stamps forbid
 overlaps the product kernel has, so read the SHARES, not the run time.
     NEXOCLOM_HIP_LIB=variants/lib_stamps.so python tools/gpu_exp_stamps.py"""
 import ctypes as C, os, sys
