@@ -294,11 +294,16 @@ class ControlPlane:
 
 # ---- sharded run -----------------------------------------------------------------------------
 def pick_device(cp, device=None):
-    """The device index of this rank: LOCAL_RANK unless given.  Never wraps ranks onto a shared
-    device."""
+    """The device index of this rank: LOCAL_RANK unless given.  A launcher that hands every
+    process its own GPU through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (one visible device
+    per process) is honoured: that device is index 0.  Ranks are never wrapped onto a shared
+    device -- ``ControlPlane.init_rccl`` compares the PCI bus ids before RCCL is asked."""
     from . import hip_api
     ndev = hip_api.device_count()
     dev = cp.local_rank if device is None else int(device)
+    masked = any(os.environ.get(k) for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'))
+    if device is None and ndev == 1 and masked:
+        dev = 0
     if not 0 <= dev < ndev:
         raise hip_api.HipError(f'rank {cp.rank}: device {dev} does not exist ({ndev} visible); '
                                'launch one process per GPU')
