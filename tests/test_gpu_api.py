@@ -438,3 +438,28 @@ def test_reference_run_inputs_end_to_end(ctx, coracle, infile):
     assert ref['counts'].sum() > 10000
     assert np.array_equal(img.packet_image, ref['counts'].astype(float))
     np.testing.assert_allclose(img.image, ref['image']*img.atoms_per_packet, rtol=1e-11)
+
+
+def test_device_sampler_refuses_unusable_tables(ctx):
+    """nxc_packets_sample fails loudly (NXC_ERR_ARG with a reason) instead of sampling from a
+    density map that is zero everywhere or a cumulative table that decreases; a map that is zero
+    almost everywhere still samples (the rejection loop is bounded and reports packets that never
+    found a launch point)."""
+    from nexoclom_amd import hip_api
+    inputs = Input(os.path.join(REF_INPUTS, 'Na.reference.input'))
+    out = Output(inputs, 10, seed=1, integrate=False, save=False)
+    src = out.source_desc()
+    bad = dict(src, surface_map=np.zeros((361, 181)))
+    with pytest.raises(hip_api.HipError, match='all zero'):
+        ctx.sample_packets(100, 1, **bad)
+    cdf, v = src['speed_table']
+    with pytest.raises(hip_api.HipError, match='non-decreasing'):
+        ctx.sample_packets(100, 1, **dict(src, speed_table=(cdf[::-1].copy(), v)))
+    with pytest.raises(hip_api.HipError, match='finite'):
+        ctx.sample_packets(100, 1, **dict(src, surface_map=np.full((361, 181), np.nan)))
+    spike = np.zeros((361, 181)); spike[100, 90] = 1.0          # one node of 65 341
+    with pytest.raises(hip_api.HipError, match='no launch point'):
+        ctx.sample_packets(20000, 1, **dict(src, surface_map=spike))
+    # a usable call afterwards still works on the same handle
+    X = ctx.sample_packets(1000, 1, download=True, **src)
+    assert np.isfinite(X).all() and np.allclose(np.linalg.norm(X[1:4], axis=0), 1.0)
