@@ -21,6 +21,7 @@
 
 #include "../../include/nexoclom_hip.h"
 #include "nxc_kernels.hpp"
+#include "nxc_log_table.hpp"
 
 namespace {
 
@@ -557,6 +558,8 @@ int nxc_create(int device, nxc_handle **out)
     if (!h) return fail(NXC_ERR_ARG, "out of host memory");
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
+    for (int i = 0; i < NXC_LOG_BINS; i++)          // the table nxc_log reads from the LDS header
+        for (int c = 0; c < 3; c++) h->header.logtab[i][c] = NXC_LOG_TABLE_DATA[i][c];
     std::snprintf(h->name, sizeof h->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
                   prop.multiProcessorCount);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1380,6 +1383,7 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
 
     // LDS block: [header space | g-value tables | spectra tile]
     std::vector<unsigned char> blob((size_t)NXC_HEADER_BYTES, 0);
+    std::memcpy(blob.data(), &h->header, sizeof(LdsHeader));      // nxc_log's table lives there
     LosK K{};
     K.sin_dphi = d->sin_dphi;
     K.sin_2dphi = d->sin_2dphi;
@@ -1562,8 +1566,9 @@ int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const 
     double *d = h->d_scratch;
     HIPCHK(hipMemcpyAsync(d, in, col, hipMemcpyHostToDevice, h->stream));
     if (in2) HIPCHK(hipMemcpyAsync(d + n, in2, col, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_math, dim3(flat_grid(h, n, 256)), dim3(256), 0, h->stream, which, n, d,
-                       d + n, d + 2 * n);
+    if (!h->d_blob && (rc = upload_blob(h))) return rc;          // the header with nxc_log's table
+    hipLaunchKernelGGL(k_math, dim3(flat_grid(h, n, 256)), dim3(256), NXC_HEADER_BYTES, h->stream,
+                       h->d_blob, which, n, d, d + n, d + 2 * n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d + 2 * n, col, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -414,6 +414,7 @@ struct WeightK {
     double rs_1e6, rs_apix;
 };
 
+constexpr int NXC_LOG_BINS = 91;
 struct LdsHeader {
     ImageK G;
     StepW W;
@@ -421,12 +422,61 @@ struct LdsHeader {
     BodyK Bd;
     LoopK L;
     WeightK Wt;
+    // table of nxc_log: {1/c, -ln(1/c) high, low, 0} per bin, 32-byte rows (one ds_read_b128 +
+    // one ds_read_b64 per lookup); filled by the host from nxc_log_table.hpp
+    alignas(32) double logtab[NXC_LOG_BINS][4];
 };
 constexpr int NXC_HEADER_BYTES = (int)((sizeof(LdsHeader) + 31) & ~size_t(31));
 
 NXC_DEV const LdsHeader &lds_header()
 {
     return *reinterpret_cast<const LdsHeader *>(nxc_lds);
+}
+
+// log(x), table-driven and division-free.  x = 2^k m with m in [OFF, 2 OFF), OFF = 181/256; bin
+// i = floor((m - OFF) * 128) has the centre c_i (bins 36..38 share c = 1); r = m / c_i - 1 comes
+// out of ONE fma with the tabulated 1/c_i (|r| <= 3/256), and
+//   log x = (k LN2_HI - ln(1/c_i)_hi) + r  [exact sum + its rounding error]
+//           + k LN2_LO - ln(1/c_i)_lo + r^2 (-1/2 + r p(r)),   p = Taylor through r^10 / 10.
+// k LN2_HI + lchi is exact (LN2_HI has 21 trailing zero bits, lchi is a multiple of 2^-42).
+// Largest error seen on 8e6 arguments (all magnitudes, dense around 1): 0.71 ulp, mean 0.25; the
+// C oracle runs the same operations on its own copy of the table.  Round 1 used fdlibm's
+// s = f / (2 + f) form: 88 issue slots with its division against 34 here.
+NXC_DEV double nxc_log(double x)
+{
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double OFF = 0.70703125;                      // 181/256, high word 0x3FE6A000
+    int k = 0;
+    // one test sends NaN, zero, negatives, infinity and subnormals to the rare path
+    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) {
+        if (x != x) return x;
+        if (x == 0.0) return -__builtin_huge_val();
+        if (x < 0.0) return __builtin_nan("");
+        if (x == __builtin_huge_val()) return x;
+        x *= 18014398509481984.0; k = -54;          // subnormal
+    }
+    const int hx = __double2hiint(x);
+    const int tmp = hx - 0x3FE6A000;                         // the low word of OFF is zero
+    k += tmp >> 20;
+    const double m = __hiloint2double(hx - (int)((unsigned)tmp & 0xFFF00000u), __double2loint(x));
+    const int i = (int)((m - OFF) * 128.0);                  // 0..90, exact
+    const int row = (int)offsetof(LdsHeader, logtab) + 32 * i;
+    const double2 t01 = lds_f64x2(row);                      // {1/c, -ln(1/c) high}
+    const double lclo = lds_f64(row + 16);
+    const double r = __builtin_fma(m, t01.x, -1.0);
+    const double kd = (double)k;
+    const double w = __builtin_fma(kd, LN2_HI, t01.y);       // exact
+    const double hi = w + r;
+    const double lo = ((w - hi) + r) + __builtin_fma(kd, LN2_LO, lclo);
+    double p = -0x1.999999999999ap-4;                        // -1/10
+    p = __builtin_fma(p, r, 0x1.c71c71c71c71cp-4);           //  1/9
+    p = __builtin_fma(p, r, -0x1.0p-3);                      // -1/8
+    p = __builtin_fma(p, r, 0x1.2492492492492p-3);           //  1/7
+    p = __builtin_fma(p, r, -0x1.5555555555555p-3);          // -1/6
+    p = __builtin_fma(p, r, 0x1.999999999999ap-3);           //  1/5
+    p = __builtin_fma(p, r, -0x1.0p-2);                      // -1/4
+    p = __builtin_fma(p, r, 0x1.5555555555555p-2);           //  1/3
+    return __builtin_fma(r * r, __builtin_fma(r, p, -0.5), lo) + hi;
 }
 NXC_DEV LdsHeader &lds_header_rw()
 {

@@ -612,9 +612,11 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
 
-__global__ void k_math(int which, int64_t n, const double *__restrict__ in,
-                       const double *__restrict__ in2, double *__restrict__ out)
+__global__ void k_math(const unsigned char *__restrict__ blob, int which, int64_t n,
+                       const double *__restrict__ in, const double *__restrict__ in2,
+                       double *__restrict__ out)
 {
+    stage_tables(blob, NXC_HEADER_BYTES);              // nxc_log reads its table from the header
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const double v = in[i];

@@ -11,8 +11,9 @@
 //
 //   nxc_cube : r^3 as an error-free (double-double) product rounded once -> correctly rounded
 //   nxc_exp : Cody-Waite reduction + Taylor polynomial in fma, no division (< 1 ulp)
-//   nxc_log : table-free range reduction + minimax polynomial of Sun's fdlibm (e_log.c;
-//             < 1 ulp), coefficients from that publication
+//   nxc_log : table-driven (91 bins of 1/128 over [181/256, 362/256), 1/c and -ln(1/c) from the
+//             LDS header), r = m/c - 1 in one fma, Taylor through r^10, no division (< 1 ulp;
+//             defined in nxc_device.hpp next to the header it reads)
 //   nxc_pow_m025 : e^-0.25 = 1 / sqrt(sqrt(e))
 #pragma once
 #include <hip/hip_runtime.h>
@@ -157,48 +158,7 @@ NXC_DEV double nxc_exp(double x)
            * 9.33263618503218878990e-302;
 }
 
-NXC_DEV double nxc_log(double x)
-{
-    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    constexpr double L1 = 6.666666666666735130e-01, L2 = 3.999999999940941908e-01,
-                     L3 = 2.857142874366239149e-01, L4 = 2.222219843214978396e-01,
-                     L5 = 1.818357216161805012e-01, L6 = 1.531383769920937332e-01,
-                     L7 = 1.479819860511658591e-01;
-    int k = 0;
-    // one test sends NaN, zero, negatives, infinity and subnormals to the rare path
-    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0)) {
-        if (x != x) return x;
-        if (x == 0.0) return -__builtin_huge_val();
-        if (x < 0.0) return __builtin_nan("");
-        if (x == __builtin_huge_val()) return x;
-        x *= 18014398509481984.0; k = -54;          // subnormal
-    }
-    unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    int hx = (int)(u >> 32);
-    k += (hx >> 20) - 1023;
-    hx &= 0x000fffff;
-    int i = (hx + 0x95f64) & 0x100000;
-    u = ((unsigned long long)(unsigned)(hx | (i ^ 0x3ff00000)) << 32) | (u & 0xffffffffull);
-    x = __longlong_as_double((long long)u);
-    k += i >> 20;
-    double f = x - 1.0, dk = (double)k;
-    if ((0x000fffff & (2 + hx)) < 3) {
-        if (f == 0.0) return k == 0 ? 0.0 : dk * LN2_HI + dk * LN2_LO;
-        double R = f * f * (0.5 - 0.33333333333333333 * f);
-        return k == 0 ? f - R : dk * LN2_HI - ((R - dk * LN2_LO) - f);
-    }
-    double s = nxc_div_mid(f, 2.0 + f), z = s * s, w = z * z;     // |f| >= 2^-20 here
-    double t1 = w * (L2 + w * (L4 + w * L6));
-    double t2 = z * (L1 + w * (L3 + w * (L5 + w * L7)));
-    double R = t2 + t1;
-    i = hx - 0x6147a;
-    int j = 0x6b851 - hx;
-    // Both tails of fdlibm, selected per lane; its k == 0 forms are the k != 0 ones with dk = +0
-    // (0 - ((a - (p + 0)) - f) == f - (a - p) bit for bit, zero results included).
-    const double hfsq = 0.5 * f * f;
-    const double tail_a = (hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f;
-    const double tail_b = (s * (f - R) - dk * LN2_LO) - f;
-    return dk * LN2_HI - ((i | j) > 0 ? tail_a : tail_b);
-}
+// nxc_log lives in nxc_device.hpp: it reads its 91-entry table from the LDS header.
+NXC_DEV double nxc_log(double x);
 
 NXC_DEV double nxc_pow_m025(double e) { return nxc_div(1.0, nxc_sqrt(nxc_sqrt(e))); }

@@ -37,8 +37,9 @@ def test_device_math_is_ieee_exact(ctx, coracle):
     assert np.array_equal(ctx.math('exp', e), coracle.math('exp', e))
     fr = np.concatenate([rng.uniform(1e-10, 1, 400000), 10**rng.uniform(-12, 3, 1000)])
     assert np.array_equal(ctx.math('log', fr), coracle.math('log', fr))
-    # the device exp/log fold fdlibm's argument ranges into one instruction stream: every range,
-    # both signs, and the neighbourhood (+-64 ulp) of every range threshold
+    # exp: every argument range, both signs, the neighbourhood (+-64 ulp) of the thresholds of its
+    # rare path and of the reduction (multiples of ln 2 / 2); log: dense around 1, every magnitude,
+    # subnormals, and +-64 ulp around every one of the 92 bin edges of its table at four scales
     def around(v, n=64):
         out = [v]
         lo = hi = v
@@ -51,7 +52,8 @@ def test_device_math_is_ieee_exact(ctx, coracle):
                         rng.choice([-1., 1.], 50000)*10**rng.uniform(-14, 0, 50000),
                         np.array([0.0, -0.0, 709.782712893384, -745.1332191019411])] +
                        [sgn*around(t) for t in (0.34657359027997264, 1.0397207708399179,
-                                                3.725290298461914e-09, 0.6931471805599453)
+                                                3.725290298461914e-09, 0.6931471805599453,
+                                                2.0794415416798357, 22.180709777918249)
                         for sgn in (-1., 1.)])
     with np.errstate(over='ignore', under='ignore'):
         assert np.array_equal(ctx.math('exp', e), coracle.math('exp', e))
@@ -64,6 +66,22 @@ def test_device_math_is_ieee_exact(ctx, coracle):
                          for sc in (0.25, 0.5, 1.0, 2.0)])
     lg = lg[lg > 0]
     assert np.array_equal(ctx.math('log', lg), coracle.math('log', lg))
+    edges = np.concatenate([sc*around((181 + 2*i)/256.0) for i in range(92)
+                            for sc in (2.0**-30, 0.5, 1.0, 2.0**40)])
+    assert np.array_equal(ctx.math('log', edges), coracle.math('log', edges))
+    # and both stay within 1 ulp of the correctly rounded values (NumPy's own are only that too)
+    with np.errstate(over='ignore', under='ignore'):
+        xs = np.concatenate([lg[np.isfinite(lg)], edges]).astype(np.longdouble)
+        ref = np.log(xs)
+        got = ctx.math('log', xs.astype(np.float64)).astype(np.longdouble)
+        ulp = np.spacing(np.abs(ref.astype(np.float64))).astype(np.longdouble)
+        ok = ref != 0
+        assert np.max(np.abs(got[ok] - ref[ok])/ulp[ok]) < 1.0
+        ee = e[np.abs(e) < 700].astype(np.longdouble)
+        refe = np.exp(ee)
+        gote = ctx.math('exp', ee.astype(np.float64)).astype(np.longdouble)
+        ulpe = np.spacing(refe.astype(np.float64)).astype(np.longdouble)
+        assert np.max(np.abs(gote - refe)/ulpe) < 1.0
 
 
 @pytest.mark.parametrize('gravity,radpres,lifetime', [
