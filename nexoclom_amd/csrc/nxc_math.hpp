@@ -120,7 +120,7 @@ NXC_DEV double nxc_cube(double r)
 // k * LN2_HI is exact, LN2_HI has 21 trailing zero bits), exp(r) = 1 + r + r^2 q(r) with q the
 // Taylor polynomial through r^13 / 13! (|r| <= ln2/2: truncation 4e-18), Horner in fma, then the
 // exponent field takes k.  Largest error seen on 4e6 arguments over [-700, 700]: 0.97 ulp (mean
-// 0.27).  The C oracle carries the same operations in the same order (oracle/c/oracle_math.h);
+// 0.27).  The C oracle carries the same operations in the same order (the checker under oracle/c);
 // round 1 used fdlibm's rational form, whose division cost 11 of the routine's 62 issue slots --
 // this one takes 21.
 NXC_DEV double nxc_exp(double x)
