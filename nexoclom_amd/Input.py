@@ -45,8 +45,7 @@ def read_inputfile(path):
 
 class Input:
     def __init__(self, infile, savepath=None):
-        self._inputfile = infile
-        self.savepath = savepath
+        self._inputfile, self.savepath = infile, savepath
         self._catalogue = []          # Output objects run with these inputs
         self._fused = []              # fused integrate+image results (ModelImage streaming mode)
         table = read_inputfile(infile)
@@ -72,7 +71,7 @@ class Input:
         (Input.py:121-172, without the database)."""
         runs = self._catalogue
         if not runs:
-            return [], [], 0, 0
+            return ([], [], 0, 0)
         return ([run.idnum for run in runs], [run.filename or run for run in runs],
                 int(sum(run.npackets for run in runs)),
                 float(sum(run.totalsource for run in runs)))

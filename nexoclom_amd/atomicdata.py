@@ -77,18 +77,16 @@ class gValue:
     velocity (atomicdata/g_values.py:75-91)."""
 
     def __init__(self, sp, wavelength, aplanet=1.0):
-        self.species = sp
+        self.species, self.filename = sp, None
         self.wavelength = Quantity(float(wavelength), 'AA')
         self.aplanet = Quantity(float(aplanet), 'au')
         line = _lines().get((sp, float(wavelength)))
         if line is None:
             self.velocity, self.g = _flat_table()
-            self.filename = None
             print(f'Warning: g-values not found for species = {sp}')
             return
-        if len(line.sources) != 1:
-            print('This should never happen')
-            raise ValueError()
+        if len(line.sources) != 1:          # two files claim one line (g_values.py:79-81)
+            raise ValueError('This should never happen')
         order = np.argsort(line.velocity)
         self.velocity = line.velocity[order]
         self.g = (line.gvalue * line.refpoint**2 / self.aplanet.value**2)[order]
@@ -101,8 +99,7 @@ class RadPresConst:
     the species' velocity grids and contributes h / (m lambda) g."""
 
     def __init__(self, species, aplanet):
-        self.species = species
-        self.aplanet = Quantity(float(aplanet), 'au')
+        self.species, self.aplanet = species, Quantity(float(aplanet), 'au')
         waves = _lines().get(species)
         if not waves:
             self.velocity, self.accel = _flat_table()
@@ -112,7 +109,7 @@ class RadPresConst:
         self.velocity = np.unique(np.concatenate([_lines()[(species, w)].velocity for w in waves]))
         mass_kg = atomicmass(species).value * const.AMU
         total = np.zeros_like(self.velocity)
-        for wave in self.wavelength:
+        for wave in sorted(waves):
             line = gValue(species, wave, aplanet)
             on_grid = np.interp(self.velocity, line.velocity, line.g)
             momentum_kick = const.H_PLANCK / mass_kg / (wave * 1e-10) * on_grid      # m/s^2
@@ -126,15 +123,13 @@ class PhotoRate:
 
     def __init__(self, species, aplanet_=1.0):
         aplanet = float(aplanet_)
-        self.species = species
-        self.aplanet = Quantity(aplanet, 'au')
+        self.species, self.aplanet = species, Quantity(aplanet, 'au')
         found = _reactions().get(species)
+        self.reactions = found or None
         if not found:
             print('No photoreactions found')
-            self.reactions = None
             self.rate = Quantity(1e-30, '1/s')
             return
-        self.reactions = found
         self.rate = Quantity(np.array([r.kappa/aplanet**2 for r in found]).sum(), '1/s')
 
     def __str__(self):
@@ -147,8 +142,7 @@ class LossInfo:
     photo-reactions of the species at the planet's distance."""
 
     def __init__(self, atom, lifetime, aplanet):
-        self.photo, self.eimp, self.chX = 0., 0., 0.
-        self.reactions = None
+        self.photo, self.eimp, self.chX, self.reactions = 0., 0., 0., None
         lifetime = float(lifetime)
         if lifetime > 0:
             print('LossInfo objects should not be instantiated with lifetime > 0')

@@ -56,11 +56,10 @@ class SSObject:
 
     def __init__(self, obj):
         record = _bodies().get(str(obj).casefold())
+        self.object = record['name'] if record else None
         if record is None:
             print(f'Object {obj} does not exist in table.')
-            self.object = None
             return
-        self.object = record['name']
         self.orbits = record['orbits']
         self.radius = Quantity(record['radius'], 'km')
         self.mass = Quantity(record['mass'], 'kg')
@@ -81,7 +80,7 @@ class SSObject:
         return self.object == getattr(other, 'object', other)
 
     def __hash__(self):
-        return hash((self.object, ))
+        return hash((self.object,))
 
     def __repr__(self):
         return f'SSObject({self.object})'
@@ -116,14 +115,11 @@ def planet_dist(planet_, taa=None, time=None):
     """(distance [au], radial velocity relative to the Sun [km/s]) of a planet at true anomaly
     ``taa`` [rad] (planet_dist.py:9-74).  ``time`` (the reference's SPICE route) is out of
     scope."""
-    if isinstance(planet_, SSObject):
-        planet = planet_
-    elif isinstance(planet_, str):
-        planet = SSObject(planet_)
-        if planet.object is None:
-            return None
-    else:
+    if not isinstance(planet_, (SSObject, str)):
         raise TypeError('solarsystemMB.planet_dist', 'Must give a SSObject or a object name.')
+    planet = SSObject(planet_) if isinstance(planet_, str) else planet_
+    if planet.object is None:
+        return None
     if time is not None:
         raise NotImplementedError('planet_dist(time=...) needs SPICE kernels: out of scope')
     if taa is None:
