@@ -19,7 +19,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'csrc', 'nxc_api.hip')
 DEPS = [os.path.join(HERE, 'csrc', f) for f in
-        ('nxc_api.hip', 'nxc_kernels.hpp', 'nxc_device.hpp', 'nxc_math.hpp')]
+        ('nxc_api.hip', 'nxc_kernels.hpp', 'nxc_device.hpp', 'nxc_math.hpp', 'nxc_log_table.hpp')]
 DEPS.append(os.path.join(os.path.dirname(HERE), 'include', 'nexoclom_hip.h'))
 OUT = os.path.join(HERE, 'lib', 'libnexoclom_hip.so')
 
