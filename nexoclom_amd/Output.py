@@ -93,16 +93,20 @@ class Output:
             self._bounce = bounce_config(inputs, self.GM, self.unit_km, seed)
             self._first_index = first_index
 
-            if inputs.options.step_size != 0:                           # Output.py:136-141
-                time = np.ones(npackets) * inputs.options.endtime.value
-            else:
-                time = self.randgen.random(npackets) * inputs.options.endtime.value
-
-            self.X0 = pd.DataFrame()
-            self.X0['time'] = time
-            self.X0['frac'] = np.ones(npackets)
             self.npackets = npackets
-            self.totalsource = self.X0['frac'].sum()
+            self.X0 = pd.DataFrame()
+            if sampler == 'device':
+                # the device draws everything, launch times included; host columns of npackets
+                # rows (0.2 s per 2e7) are built only when the caller wants X0 back
+                self.totalsource = float(npackets)
+            else:
+                if inputs.options.step_size != 0:                       # Output.py:136-141
+                    time = np.ones(npackets) * inputs.options.endtime.value
+                else:
+                    time = self.randgen.random(npackets) * inputs.options.endtime.value
+                self.X0['time'] = time
+                self.X0['frac'] = np.ones(npackets)
+                self.totalsource = self.X0['frac'].sum()
 
             # The reference stops here for any planet with moons ('Not set up',
             # Output.py:153-155).  EXTENSION: included moons pull on and absorb packets, a moon
