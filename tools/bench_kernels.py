@@ -8,6 +8,7 @@
   k_los          f-1       line-of-sight cones ((spectrum, sample) pair tests)
   k_sample       f-4       initial states on the device (64 B written per packet)
   k_speed_max / k_order_hist / k_order_scatter   queue order of the resident packets
+  k_const_fused  a-1..a-3  the STRESS vector of SURVEY 8(d): every packet alive for all 1667 steps
 
 One JSON line per kernel: HIP-event time of the launch on the handle's stream, units, the
 algorithmic bytes of SURVEY.md section 8(d) (or of DESIGN.md section 3 for the rows this survey
@@ -141,6 +142,37 @@ def main():
     print(json.dumps({'kernel': 'nxc_packets_upload', 'call_ms': up_ms, 'packets': soa.shape[1],
                       'note': 'H2D of 64 B/packet from pageable memory + k_speed_max + '
                               'k_order_hist + k_order_scatter'}))
+
+    # ---- SURVEY 8(d)'s stress vector: no early deaths, so no refill, no empty lanes, no queue
+    # order -- the step loop's own rate.  Packets start at rest 30 R from the planet, outside its
+    # shadow, and the outer edge is moved out of reach; radiation pressure carries them off.
+    ns = 5*256*768          # five packets per resident lane: every lane does the same work
+    rng = np.random.default_rng(5)
+    phi = rng.uniform(0, 2*np.pi, ns)
+    stress = np.zeros((8, ns))
+    stress[0] = opt.endtime.value
+    stress[1], stress[2], stress[3] = 30*np.cos(phi), rng.uniform(-5, 5, ns), 30*np.sin(phi)
+    stress[5] = rng.uniform(-2, 2, ns)/out.unit_km          # a spread of Doppler shifts
+    stress[7] = 1.0
+    ctx.set_forces(**out.forces_kwargs())
+    ctx.upload_soa(stress)
+    for _ in range(reps):
+        ctx.integrate_const(opt.step_size, n_iter, 1e9)
+        ms = ctx.last_kernel_ms()
+    c = ctx.counters()
+    line('k_const_fused<no image> stress', ms, c['particle_steps'], 'particle*steps', 128,
+         f'{ns} packets x {n_iter} steps, none dies (SURVEY 8d stress vector)')
+    with quiet():
+        img = ModelImage(inputs, {'quantity': 'radiance', 'dims': '512,512'}, context=ctx)
+    img._set_image(ctx, float(out.aplanet), float(out.vrplanet), True)
+    for _ in range(reps):
+        ctx.image_clear()
+        ctx.integrate_const(opt.step_size, n_iter, 1e9, image=True)
+        ms = ctx.last_kernel_ms()
+    c = ctx.counters()
+    line('k_const_fused<IMAGE> stress', ms, c['particle_steps'], 'particle*steps', 128,
+         f'same packets, every sample located, {c["samples_binned"]} of {c["samples"]} inside '
+         f'the image (the packets are far from it): the locate stage without weights and atomics')
 
     inputs.options.step_size = 0.
     inputs.options.resolution = 1e-4
