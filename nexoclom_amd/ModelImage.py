@@ -198,8 +198,15 @@ class ModelImage(ModelResult):
     # ---- GPU plumbing ---------------------------------------------------------------------
     def context(self):
         if self._ctx is None:
-            from . import hip_api
-            self._ctx = hip_api.Context(self._device)
+            # the device the catalogued runs were made on, when there is one (a new handle costs
+            # 0.1 s); else a fresh one
+            shared = [getattr(run, '_ctx', None) for run in getattr(self.inputs, '_catalogue', ())]
+            shared = [ctx for ctx in shared if ctx is not None and getattr(ctx, '_h', True)]
+            if shared:
+                self._ctx = shared[-1]
+            else:
+                from . import hip_api
+                self._ctx = hip_api.Context(self._device)
         return self._ctx
 
     def image_rotation(self):
@@ -218,18 +225,17 @@ class ModelImage(ModelResult):
                       self.xedges, self.zedges, self.g_tables(aplanet), downcast_f32=downcast)
 
     def create_image(self, output):
-        """ModelImage.py:229-274 for one catalogued Output (or .npz path): restore, rotate, mask,
-        weight and histogram -- the last four inside one HIP kernel."""
+        """ModelImage.py:229-274 for one catalogued Output (or .npz path): the restored sample
+        columns are rotated, masked, weighted and binned inside one HIP kernel."""
         from .Output import Output
-        output = Output.restore(output)
-        rows = output.X
-        if len(rows) == 0 or 'x' not in rows:
+        samples, aplanet, vrplanet_kms = Output.image_columns(output)
+        if samples is None or len(samples[0]) == 0:
             raise ValueError('this Output holds no trajectory (it was run with '
                              'keep_trajectory=False); use ModelImage(..., npackets=N) instead')
         ctx = self.context()
-        vr = float(output.vrplanet)/self.unit_km          # km/s -> R/s (ModelImage.py:242-243)
-        self._set_image(ctx, float(output.aplanet), vr, downcast=False)
-        ctx.image_accumulate(*(rows[c].values for c in ('x', 'y', 'z', 'vy', 'frac')))
+        vr = vrplanet_kms/self.unit_km                     # km/s -> R/s (ModelImage.py:242-243)
+        self._set_image(ctx, aplanet, vr, downcast=False)
+        ctx.image_accumulate(*samples)
         self.counters = ctx.counters()
         assert self.counters['nonfinite'] == 0, 'Non-finite weights'
         image, counts = ctx.image_download()

@@ -32,6 +32,9 @@ from .source_distribution import (angular_distribution, speed_distribution,
 from .units import Quantity, register_unit
 
 STATE_COLS = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']
+# save()'s 32-bit down-cast and restore()'s way back (Output.py:528-543, 555-570)
+NARROW = {np.int64: np.int32, np.float64: np.float32}
+WIDE = {np.int32: np.int64, np.float32: np.float64}
 
 
 def n_output_steps(endtime, step):
@@ -325,15 +328,15 @@ class Output:
             self._raise_on_counters(ctr)
             assert ctr.get('unfinished', 0) == 0, 'row passes disagree'
             rows, lengths = res['rows'], res['lengths']
-            X = pd.DataFrame()
-            X['Index'] = np.repeat(np.arange(n, dtype=np.int64), lengths)
-            for k, name in enumerate(STATE_COLS):
-                X[name] = rows[k]
-            X['lossfrac'] = rows[8]
+            index = np.repeat(np.arange(n, dtype=np.int64), lengths)
             # the frac > 0 filter leaves the surviving rows' original labels (packet*nsteps + ct)
             starts = np.cumsum(lengths) - lengths
-            X.index = (X['Index'].values*self.nsteps
-                       + (np.arange(len(X), dtype=np.int64) - np.repeat(starts, lengths)))
+            labels = index*self.nsteps + (np.arange(len(index), dtype=np.int64)
+                                          - np.repeat(starts, lengths))
+            columns = {'Index': index}
+            columns.update((name, rows[k]) for k, name in enumerate(STATE_COLS))
+            columns['lossfrac'] = rows[8]
+            X = pd.DataFrame(columns, index=pd.Index(labels), copy=False)   # one frame, no copies
             self.X = X
         elif keep_trajectory:
             res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)
@@ -398,12 +401,7 @@ class Output:
             keep = self.X.frac.values > 0
             if not keep.all():          # the compact-rows path already delivers only these rows
                 self.X = self.X[keep]
-        for frame in (self.X0, self.X):
-            for column in frame:
-                if frame[column].dtype == np.int64:
-                    frame[column] = frame[column].astype(np.int32)
-                elif frame[column].dtype == np.float64:
-                    frame[column] = frame[column].astype(np.float32)
+        self.X0, self.X = self._recast(self.X0, NARROW), self._recast(self.X, NARROW)
         catalogue = getattr(self.inputs, '_catalogue', None)
         if catalogue is not None:
             self.idnum = len(catalogue) + 1
@@ -422,22 +420,46 @@ class Output:
                  vrplanet_kms=float(self.vrplanet), compress=self.compress, **data)
 
     @staticmethod
-    def upcast(frame):
+    def _recast(frame, table):
+        """The frame with every column whose dtype is a key of ``table`` converted; built in one
+        go (assigning the columns back one by one costs pandas a copy and a cache flush each)."""
+        if not len(frame.columns) or not any(frame[c].dtype.type in table for c in frame):
+            return frame
+        columns = {c: (frame[c].values.astype(table[frame[c].dtype.type])
+                       if frame[c].dtype.type in table else frame[c].values) for c in frame}
+        return pd.DataFrame(columns, index=frame.index, copy=False)
+
+    @classmethod
+    def upcast(cls, frame):
         """restore()'s 32 -> 64 bit conversion (Output.py:555-570)."""
-        for column in frame:
-            if frame[column].dtype == np.int32:
-                frame[column] = frame[column].astype(np.int64)
-            elif frame[column].dtype == np.float32:
-                frame[column] = frame[column].astype(np.float64)
-        return frame
+        return cls._recast(frame, WIDE)
+
+    IMAGE_COLS = ('x', 'y', 'z', 'vy', 'frac')
+
+    @classmethod
+    def image_columns(cls, source):
+        """What create_image needs of a stored Output, without restoring the rest: the five
+        sample columns as restore() would deliver them (64-bit copies of the stored 32-bit
+        values, Output.py:555-570), aplanet [au] and vrplanet [km/s].  ``source``: a catalogued
+        Output or an .npz path."""
+        if isinstance(source, cls):
+            frame = source.X
+            if len(frame) == 0 or 'x' not in frame:
+                return None, float(source.aplanet), float(source.vrplanet)
+            columns = [np.asarray(frame[c].values, dtype=np.float64) for c in cls.IMAGE_COLS]
+            return columns, float(source.aplanet), float(source.vrplanet)
+        with np.load(source, allow_pickle=False) as data:
+            if 'X.x' not in data.files:
+                return None, float(data['aplanet']), float(data['vrplanet_kms'])
+            columns = [np.asarray(data['X.' + c], dtype=np.float64) for c in cls.IMAGE_COLS]
+            return columns, float(data['aplanet']), float(data['vrplanet_kms'])
 
     @classmethod
     def restore(cls, source):
         """Return an Output with 64-bit columns from a catalogued Output or an .npz file."""
         if isinstance(source, cls):
             out = source
-            cls.upcast(out.X0)
-            cls.upcast(out.X)
+            out.X0, out.X = cls.upcast(out.X0), cls.upcast(out.X)
             return out
         data = np.load(source, allow_pickle=False)
         out = cls.__new__(cls)
@@ -450,6 +472,5 @@ class Output:
         out.compress = bool(data['compress'])
         out.X0 = pd.DataFrame({k[3:]: data[k] for k in data.files if k.startswith('X0.')})
         out.X = pd.DataFrame({k[2:]: data[k] for k in data.files if k.startswith('X.')})
-        cls.upcast(out.X0)
-        cls.upcast(out.X)
+        out.X0, out.X = cls.upcast(out.X0), cls.upcast(out.X)
         return out
