@@ -99,14 +99,17 @@ class Input:
         return int(math.ceil(1024**3/records/8))
 
     def run(self, npackets, packs_per_it=None, overwrite=False, compress=True,
-            distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None):
+            distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None,
+            sampler='numpy'):
         """Integrate until the catalogue holds ``npackets`` packets (Input.py:175-268).
 
         Every pass plans ``ceil(todo / size)`` Outputs of ``size = min(todo, chunk_size)``
         packets -- the reference's arithmetic, so the last Output of a pass may overshoot.  With a
         ``seed`` the k-th Output of this call is drawn from ``seed + k``: Output 0 is the
         reference's stream; the reference itself passes the same seed to every Output
-        (Input.py:246), which repeats identical packets."""
+        (Input.py:246), which repeats identical packets.  ``sampler='device'`` draws the initial
+        states on the GPU instead (counter-based: the k-th Output continues the index space of
+        the ones before it under the one ``seed``)."""
         from .Output import Output
         started = time.time()
         if distribute in (True, 'delay', 'delayed'):
@@ -116,6 +119,7 @@ class Input:
         have = self._report()
         want = int(npackets)
         made = 0
+        drawn = have                             # device sampler: next free global packet index
         while have < want:
             todo = want - have
             size = min(todo, self.chunk_size(packs_per_it))
@@ -125,9 +129,13 @@ class Input:
             for number in range(1, passes + 1):
                 print(f'Starting iteration #{number} of {passes}')
                 tick = time.time()
-                out = Output(self, size, compress=compress,
-                             seed=None if seed is None else seed + made, device=device,
-                             keep_trajectory=keep_trajectory, context=context)
+                if sampler == 'device':
+                    draw = dict(seed=seed, sampler='device', first_index=drawn)
+                else:
+                    draw = dict(seed=None if seed is None else seed + made)
+                out = Output(self, size, compress=compress, device=device,
+                             keep_trajectory=keep_trajectory, context=context, **draw)
+                drawn += size
                 context = out.context()          # every Output of the run shares one device
                 made += 1
                 print(f'Completed iteration #{number} in {time.time() - tick} seconds.')

@@ -1,5 +1,7 @@
 """The drop-in boundary on a real GPU: Input / Output / ModelImage used the way a nexoclom user
 (and the reference's own tests) use them."""
+import contextlib
+import io
 import os
 
 import numpy as np
@@ -117,6 +119,30 @@ def test_modelimage_two_stage_equals_streaming_equals_oracle(ctx, quantity):
     np.testing.assert_allclose(two_stage.image, image*two_stage.atoms_per_packet, rtol=1e-11)
     assert np.allclose(two_stage.xaxis, ex[:-1] + (ex[1]-ex[0])/2)
     assert two_stage.atoms_per_packet == 1e23/(3000*401/12000.)
+
+
+def test_input_run_with_the_device_sampler_continues_one_index_space(ctx):
+    """Input.run(sampler='device'): the Outputs of a run take consecutive slices of one
+    counter space, so the catalogue holds exactly the packets one big device draw would give and
+    the two-stage image equals the streaming image of the same seed."""
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    inputs.options.endtime = type(inputs.options.endtime)(9000., 's')
+    inputs.run(5000, packs_per_it=2000, seed=3, context=ctx, sampler='device')   # 2000+2000+1000
+    assert [len(o) for o in inputs._catalogue] == [2000, 2000, 1000]
+    with contextlib.redirect_stdout(io.StringIO()):
+        whole = Output(inputs, 5000, seed=3, integrate=False, save=False, context=ctx,
+                       sampler='device')
+    for c in ('x', 'vy', 'time'):
+        stored = np.concatenate([o.X0[c].values for o in inputs._catalogue])
+        assert np.array_equal(stored, whole.X0[c].values.astype(np.float32)), c
+    params = {'quantity': 'radiance', 'dims': '64,64'}
+    two_stage = inputs.produce_image(params, context=ctx)
+    streaming = ModelImage(inputs, params, npackets=5000, packs_per_it=2000, seed=3, context=ctx,
+                           sampler='device')
+    assert two_stage.totalsource == streaming.totalsource
+    assert np.array_equal(two_stage.packet_image, streaming.packet_image)
+    np.testing.assert_allclose(two_stage.image, streaming.image, rtol=1e-11)
+    assert two_stage.packet_image.sum() > 1000
 
 
 def _orbit(nspec, seed=0):
