@@ -283,6 +283,11 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
  * Adds to the resident image pair (use nxc_image_clear / nxc_image_download around it). */
 int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
                          const double *z, const double *vy, const double *frac);
+/* The same for samples in the 32-bit form Output.save() stores them in (Output.py:528-543): what
+ * restore()'s up-cast (Output.py:555-570) followed by nxc_image_accumulate gives, bit for bit,
+ * with half the host-to-device bytes and no 64-bit copy on the host. */
+int nxc_image_accumulate_f32(nxc_handle *h, int64_t p, const float *x, const float *y,
+                             const float *z, const float *vy, const float *frac);
 
 /* ---- f-1: spacecraft line-of-sight cones ----------------------------------------------------------
  * For each of S spectra (spacecraft position + boresight) sum weight/Apix over the stored samples

@@ -439,19 +439,19 @@ class Output:
     @classmethod
     def image_columns(cls, source):
         """What create_image needs of a stored Output, without restoring the rest: the five
-        sample columns as restore() would deliver them (64-bit copies of the stored 32-bit
-        values, Output.py:555-570), aplanet [au] and vrplanet [km/s].  ``source``: a catalogued
-        Output or an .npz path."""
+        sample columns as stored (32-bit after save(); the device widens them exactly like
+        restore()'s up-cast, Output.py:555-570), aplanet [au] and vrplanet [km/s].  ``source``: a
+        catalogued Output or an .npz path."""
         if isinstance(source, cls):
             frame = source.X
             if len(frame) == 0 or 'x' not in frame:
                 return None, float(source.aplanet), float(source.vrplanet)
-            columns = [np.asarray(frame[c].values, dtype=np.float64) for c in cls.IMAGE_COLS]
+            columns = [frame[c].values for c in cls.IMAGE_COLS]
             return columns, float(source.aplanet), float(source.vrplanet)
         with np.load(source, allow_pickle=False) as data:
             if 'X.x' not in data.files:
                 return None, float(data['aplanet']), float(data['vrplanet_kms'])
-            columns = [np.asarray(data['X.' + c], dtype=np.float64) for c in cls.IMAGE_COLS]
+            columns = [data['X.' + c] for c in cls.IMAGE_COLS]
             return columns, float(data['aplanet']), float(data['vrplanet_kms'])
 
     @classmethod

@@ -519,6 +519,34 @@ int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double 
     return NXC_OK;
 }
 
+// a-6..a-8 over stored samples, 64-bit or as save() keeps them (32-bit)
+template <typename T>
+int image_accumulate(nxc_handle *h, int64_t p, const T *x, const T *y, const T *z, const T *vy,
+                     const T *frac)
+{
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    if (p < 0 || (p && (!x || !y || !z || !vy || !frac))) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    if (p == 0) return NXC_OK;
+    const size_t col = (size_t)p * sizeof(T);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 5 * col);
+    if (rc) return rc;
+    T *d = reinterpret_cast<T *>(h->d_scratch);
+    const T *src[5] = {x, y, z, vy, frac};
+    for (int c = 0; c < 5; c++)
+        HIPCHK(hipMemcpyAsync(d + c * p, src[c], col, hipMemcpyHostToDevice, h->stream));
+    if ((rc = prep_kernel(k_image<T>, h->all_bytes))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(k_image<T>, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
+                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
+                       d + 3 * p, d + 4 * p, h->d_image, h->d_ctr);
+    HIPCHK(hipGetLastError());
+    if ((rc = end_timed(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -1340,29 +1368,13 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
 int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
                          const double *z, const double *vy, const double *frac)
 {
-    return guarded([&]() -> int {
-    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
-    HIPCHK(hipSetDevice(h->device));
-    if (p < 0 || (p && (!x || !y || !z || !vy || !frac))) return fail(NXC_ERR_ARG, "bad arguments");
-    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
-    if (p == 0) return NXC_OK;
-    const size_t col = (size_t)p * sizeof(double);
-    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 5 * col);
-    if (rc) return rc;
-    double *d = h->d_scratch;
-    const double *src[5] = {x, y, z, vy, frac};
-    for (int c = 0; c < 5; c++)
-        HIPCHK(hipMemcpyAsync(d + c * p, src[c], col, hipMemcpyHostToDevice, h->stream));
-    if ((rc = prep_kernel(k_image, h->all_bytes))) return rc;
-    if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(k_image, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
-                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
-                       d + 3 * p, d + 4 * p, h->d_image, h->d_ctr);
-    HIPCHK(hipGetLastError());
-    if ((rc = end_timed(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return NXC_OK;
-    });
+    return guarded([&]() -> int { return image_accumulate(h, p, x, y, z, vy, frac); });
+}
+
+int nxc_image_accumulate_f32(nxc_handle *h, int64_t p, const float *x, const float *y,
+                             const float *z, const float *vy, const float *frac)
+{
+    return guarded([&]() -> int { return image_accumulate(h, p, x, y, z, vy, frac); });
 }
 
 int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,

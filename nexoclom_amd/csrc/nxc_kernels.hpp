@@ -588,10 +588,13 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// T = double, or float for samples handed over as the reference stores them (Output.py:528-543);
+// widening a float is exact, so both give the same image.
+template <typename T>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
-        const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-        const double *__restrict__ vy, const double *__restrict__ frac,
+        const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z,
+        const T *__restrict__ vy, const T *__restrict__ frac,
         double *__restrict__ acc2, DevCounters *__restrict__ ctr)
 {
     stage_tables(blob, stage_bytes);

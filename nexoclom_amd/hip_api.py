@@ -22,6 +22,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_set_image', 'nxc_state', 'nxc_rk5_step', 'nxc_packets_upload', 'nxc_image_clear',
            'nxc_image_download', 'nxc_counters_get', 'nxc_last_kernel_ms', 'nxc_integrate_const',
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
+           'nxc_image_accumulate_f32',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
            'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
@@ -389,7 +390,15 @@ class Context:
 
     # -- a-6..a-8 ---------------------------------------------------------------------------
     def image_accumulate(self, x, y, z, vy, frac):
-        x, y, z, vy, frac = map(_f64, (x, y, z, vy, frac))
+        """Bin stored samples.  Five float32 columns (an Output as save() keeps it) go to the
+        device as they are and are widened there; anything else is taken as float64."""
+        cols = (x, y, z, vy, frac)
+        if all(getattr(c, 'dtype', None) == np.float32 for c in cols):
+            cols = [np.ascontiguousarray(c) for c in cols]
+            ptr = [c.ctypes.data_as(C.POINTER(C.c_float)) for c in cols]
+            self._check(self.lib.nxc_image_accumulate_f32(self._h, C.c_int64(len(cols[0])), *ptr))
+            return
+        x, y, z, vy, frac = map(_f64, cols)
         self._check(self.lib.nxc_image_accumulate(self._h, C.c_int64(len(x)), _p(x), _p(y), _p(z),
                                                   _p(vy), _p(frac)))
 

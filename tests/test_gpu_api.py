@@ -127,17 +127,18 @@ def test_input_run_with_the_device_sampler_continues_one_index_space(ctx):
     the two-stage image equals the streaming image of the same seed."""
     inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
     inputs.options.endtime = type(inputs.options.endtime)(9000., 's')
-    inputs.run(5000, packs_per_it=2000, seed=3, context=ctx, sampler='device')   # 2000+2000+1000
-    assert [len(o) for o in inputs._catalogue] == [2000, 2000, 1000]
+    # the reference's chunk arithmetic: ceil(5000/2000) Outputs of 2000 packets (Input.py:228-230)
+    inputs.run(5000, packs_per_it=2000, seed=3, context=ctx, sampler='device')
+    assert [len(o) for o in inputs._catalogue] == [2000, 2000, 2000]
     with contextlib.redirect_stdout(io.StringIO()):
-        whole = Output(inputs, 5000, seed=3, integrate=False, save=False, context=ctx,
+        whole = Output(inputs, 6000, seed=3, integrate=False, save=False, context=ctx,
                        sampler='device')
     for c in ('x', 'vy', 'time'):
         stored = np.concatenate([o.X0[c].values for o in inputs._catalogue])
         assert np.array_equal(stored, whole.X0[c].values.astype(np.float32)), c
     params = {'quantity': 'radiance', 'dims': '64,64'}
     two_stage = inputs.produce_image(params, context=ctx)
-    streaming = ModelImage(inputs, params, npackets=5000, packs_per_it=2000, seed=3, context=ctx,
+    streaming = ModelImage(inputs, params, npackets=6000, packs_per_it=2000, seed=3, context=ctx,
                            sampler='device')
     assert two_stage.totalsource == streaming.totalsource
     assert np.array_equal(two_stage.packet_image, streaming.packet_image)

@@ -196,6 +196,30 @@ def test_image_kernel_matches_numpy_histogram(ctx, coracle):
     np.testing.assert_allclose(image, ref_img, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize('quantity', ['radiance', 'column'])
+def test_image_kernel_on_float32_samples_equals_the_restored_path(ctx, quantity):
+    """nxc_image_accumulate_f32 (samples as Output.save() stores them) against restore()'s 64-bit
+    up-cast followed by nxc_image_accumulate: same pixels, same counts, the same weights (one
+    sample per pixel-and-lane order aside: atomics), NaN and out-of-range samples included."""
+    f = H.mercury_forces('Na', 1.3)
+    p = 200001
+    X = H.random_cloud(p, 33).astype(np.float32)
+    cols = [np.ascontiguousarray(X[:, c]) for c in (1, 2, 3, 5, 7)]
+    cols[0][:7] = [np.nan, np.inf, -np.inf, 4.0, -4.0, 3.9999998, 1e30]
+    im = H.image_setup(f, quantity, dims=(200, 120), width=(8., 6.))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], quantity, im['xedges'], im['zedges'],
+                  im['g_tables'])
+    ctx.image_accumulate(*cols)                                    # float32 entry point
+    img32, cnt32 = ctx.image_download()
+    ctr32 = ctx.counters()
+    ctx.image_clear()
+    ctx.image_accumulate(*(c.astype(np.float64) for c in cols))
+    img64, cnt64 = ctx.image_download()
+    assert ctr32 == ctx.counters() and ctr32['samples'] == p
+    assert np.array_equal(cnt32, cnt64) and cnt64.sum() > 1000
+    np.testing.assert_allclose(img32, img64, rtol=1e-12, atol=0)
+
+
 def test_variable_driver_bit_exact(ctx, coracle):
     f = H.mercury_forces('Na', 1.3)
     H.set_ctx_forces(ctx, f)
