@@ -78,16 +78,21 @@ def los_geometry(data, outeredge, dphi):
         planet_size = np.arcsin(1. / dist_from_plan)
     dist_from_plan = np.where(off_centre > planet_size, 1e30, dist_from_plan)
     step = np.sin(dphi)
-    ladders = []
-    for x_sc, bore in zip(at, look):
+    far = np.empty(len(at))
+    for k, (x_sc, bore) in enumerate(zip(at, look)):
         # far root of |x_sc + t bore| = outeredge
         b = 2*np.sum(x_sc*bore)
         c = np.linalg.norm(x_sc)**2 - outeredge**2
         with np.errstate(invalid='ignore'):
-            far = (-b + np.sqrt(b**2 - 4*1*c))/2
-        ladders.append(ladder_to(far, step, step))
-    lengths = np.array([len(t) for t in ladders], dtype=np.int64)
-    return dist_from_plan, lengths, np.array(max(ladders, key=len))
+            far[k] = (-b + np.sqrt(b**2 - 4*1*c))/2
+    # every spectrum climbs the same rungs and stops at its own `far`: one ladder to the largest,
+    # a spectrum's length = the rungs below its limit plus the one that reaches it (a line that
+    # never meets the sphere has a NaN root and, like the reference's loop, just the first rung)
+    reach = np.nanmax(far) if np.isfinite(far).any() else step
+    ladder = np.array(ladder_to(reach, step, step))
+    lengths = np.where(np.isnan(far), 1, np.searchsorted(ladder, far, side='left') + 1)
+    lengths = np.minimum(lengths, len(ladder)).astype(np.int64)
+    return dist_from_plan, lengths, ladder[:lengths.max()]
 
 
 class LOSResult(ModelResult):
@@ -109,6 +114,7 @@ class LOSResult(ModelResult):
         self.label = kwargs.get('label', 'LOSResult')
         self._ctx, self._device = context, device
         self.iterations = []
+        self._geometry = None
 
     def context(self):
         if self._ctx is None:
@@ -119,9 +125,14 @@ class LOSResult(ModelResult):
     def compute_iteration(self, output, scdata, used_cap=0):
         """One catalogued Output against all spectra (compute_iteration.py:90-240)."""
         from .Output import Output
-        output = Output.restore(output)
+        if not isinstance(output, Output):       # a file; a catalogued Output is used as stored:
+            output = Output.restore(output)      # the binding widens just the columns it sends
         samples, spectra = output.X, scdata.data
-        cut, lengths, ladder = los_geometry(spectra, self.inputs.options.outeredge, self.dphi)
+        if self._geometry is None or self._geometry[0] is not spectra:
+            # the same for every Output of a run (compute_iteration.py recomputes it per file)
+            self._geometry = (spectra, los_geometry(spectra, self.inputs.options.outeredge,
+                                                    self.dphi))
+        cut, lengths, ladder = self._geometry[1]
         sc = np.vstack([spectra[list(POSITION + BORESIGHT)].values.T.astype(float), cut,
                         lengths.astype(float)])
         if 'Index' in samples.columns:
