@@ -270,6 +270,10 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
 int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                              int64_t *lengths_out, int64_t *total_out);
 int nxc_rows_fetch(nxc_handle *h, double *rows_out);
+/* The same rows narrowed to float32 on the device, host [9][total] floats: what save()'s down-cast
+ * (Output.py:528-543, which every reference Output ends in, Output.py:202) makes of them, at half
+ * the device-to-host bytes. */
+int nxc_rows_fetch_f32(nxc_handle *h, float *rows_out);
 /* Same launch without any host transfer or synchronisation (bench / pipelining). */
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags);

@@ -54,6 +54,9 @@ class Output:
                  sampler='numpy', first_index=0, materialize_x0=True):
         self.inputs = inputs
         self.planet = inputs.geometry.planet
+        # a finished reference Output always went through save() (Output.py:202): its frames are
+        # 32-bit.  When this one will too, the rows can leave the device already narrowed.
+        self._narrow_rows = bool(save and integrate and run_model)
         self._ctx = context
         self._device = device
         self.filename = None
@@ -323,16 +326,17 @@ class Output:
             # compress=True keeps only the rows with frac > 0 (Output.py:523-524, applied by the
             # save() every reference Output ends in): the kernel delivers exactly those rows,
             # packet-major like the filtered frame, instead of the >90 % zero-padded dense array
-            res = ctx.integrate_const_rows(step, n_iter, opt.outeredge)
+            res = ctx.integrate_const_rows(step, n_iter, opt.outeredge, narrow=self._narrow_rows)
             ctr = ctx.counters()
             self._raise_on_counters(ctr)
             assert ctr.get('unfinished', 0) == 0, 'row passes disagree'
             rows, lengths = res['rows'], res['lengths']
-            index = np.repeat(np.arange(n, dtype=np.int64), lengths)
             # the frac > 0 filter leaves the surviving rows' original labels (packet*nsteps + ct)
             starts = np.cumsum(lengths) - lengths
-            labels = index*self.nsteps + (np.arange(len(index), dtype=np.int64)
-                                          - np.repeat(starts, lengths))
+            labels = np.repeat(np.arange(n, dtype=np.int64)*self.nsteps - starts, lengths)
+            labels += np.arange(len(labels), dtype=np.int64)
+            index = np.repeat(np.arange(n, dtype=np.int32 if self._narrow_rows else np.int64),
+                              lengths)
             columns = {'Index': index}
             columns.update((name, rows[k]) for k, name in enumerate(STATE_COLS))
             columns['lossfrac'] = rows[8]

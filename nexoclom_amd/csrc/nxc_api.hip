@@ -519,6 +519,76 @@ int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double 
     return NXC_OK;
 }
 
+// pass 2 of the compact-rows protocol; narrow: the rows leave as float32 (save()'s down-cast)
+int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
+{
+    int rc = need_forces(h);
+    if (rc) return rc;
+    const int64_t n = h->n_packets;
+    if (h->rows_total < 0 || h->rows_n != n)
+        return fail(NXC_ERR_STATE, "nxc_rows_fetch needs a preceding nxc_integrate_const_rows");
+    const long long total = h->rows_total;
+    h->rows_total = -1;
+    if (total == 0) return NXC_OK;
+    if (!rows_out) return fail(NXC_ERR_ARG, "rows_out is null");
+    const size_t bytes = (size_t)9 * (size_t)total * sizeof(double);
+    const size_t out_bytes = narrow ? bytes / 2 : bytes;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + (narrow ? out_bytes : 0) > free_b)
+        return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
+                                 "per call (the reference chunks too, Input.py:219-222)");
+    if (h->have_bodies) {
+        if (h->have_bounce)
+            return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
+        if ((rc = upload_moon_table(h, h->rows_step, h->rows_n_iter))) return rc;
+    }
+    double *d_rows = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rows), bytes + (narrow ? out_bytes : 0)));
+    float *d_narrow = reinterpret_cast<float *>(d_rows + (size_t)9 * (size_t)total);
+    if ((rc = upload_step(h, h->rows_step))) { (void)hipFree(d_rows); return rc; }
+    hipError_t e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
+    const size_t lds = h->force_bytes;
+    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
+    const double edge2 = sqrt_threshold(h->rows_edge);
+    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+    if (e == hipSuccess) {
+#define NXC_LAUNCH_ROWS(BOUNCE, NBODY)                                                          \
+    do {                                                                                        \
+        auto kernel = k_const_rows<BOUNCE, NBODY>;                                              \
+        rc = prep_kernel(kernel, lds);                                                          \
+        if (!rc)                                                                                \
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F,       \
+                               h->d_blob, (int64_t)lds, n, h->d_packets, h->first_id,           \
+                               h->rows_n_iter, edge2, h->d_offsets, total, d_rows, h->d_ctr,    \
+                               NBODY ? h->d_moonpos : (const double *)nullptr);                 \
+    } while (0)
+        if (h->have_bodies) NXC_LAUNCH_ROWS(false, true);
+        else if (h->have_bounce) NXC_LAUNCH_ROWS(true, false);
+        else NXC_LAUNCH_ROWS(false, false);
+#undef NXC_LAUNCH_ROWS
+        if (!rc) e = hipGetLastError();
+    }
+    if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess && !rc) {
+        h->timed = true;
+        if (narrow) {
+            const int64_t cells = (int64_t)9 * total;
+            hipLaunchKernelGGL(k_narrow_f32, dim3(flat_grid(h, cells, NXC_BLOCK)), dim3(NXC_BLOCK),
+                               0, h->stream, d_rows, d_narrow, cells);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(rows_out, narrow ? static_cast<const void *>(d_narrow) : d_rows,
+                               out_bytes, hipMemcpyDeviceToHost, h->stream);
+    }
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_rows);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
+    return NXC_OK;
+}
+
 // a-6..a-8 over stored samples, 64-bit or as save() keeps them (32-bit)
 template <typename T>
 int image_accumulate(nxc_handle *h, int64_t p, const T *x, const T *y, const T *z, const T *vy,
@@ -1269,63 +1339,12 @@ int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double 
 
 int nxc_rows_fetch(nxc_handle *h, double *rows_out)
 {
-    return guarded([&]() -> int {
-    int rc = need_forces(h);
-    if (rc) return rc;
-    const int64_t n = h->n_packets;
-    if (h->rows_total < 0 || h->rows_n != n)
-        return fail(NXC_ERR_STATE, "nxc_rows_fetch needs a preceding nxc_integrate_const_rows");
-    const long long total = h->rows_total;
-    h->rows_total = -1;
-    if (total == 0) return NXC_OK;
-    if (!rows_out) return fail(NXC_ERR_ARG, "rows_out is null");
-    const size_t bytes = (size_t)9 * (size_t)total * sizeof(double);
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (bytes > free_b)
-        return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
-                                 "per call (the reference chunks too, Input.py:219-222)");
-    if (h->have_bodies) {
-        if (h->have_bounce)
-            return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
-        if ((rc = upload_moon_table(h, h->rows_step, h->rows_n_iter))) return rc;
-    }
-    double *d_rows = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rows), bytes));
-    if ((rc = upload_step(h, h->rows_step))) { (void)hipFree(d_rows); return rc; }
-    hipError_t e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
-    const size_t lds = h->force_bytes;
-    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
-    const double edge2 = sqrt_threshold(h->rows_edge);
-    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
-    if (e == hipSuccess) {
-#define NXC_LAUNCH_ROWS(BOUNCE, NBODY)                                                          \
-    do {                                                                                        \
-        auto kernel = k_const_rows<BOUNCE, NBODY>;                                              \
-        rc = prep_kernel(kernel, lds);                                                          \
-        if (!rc)                                                                                \
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F,       \
-                               h->d_blob, (int64_t)lds, n, h->d_packets, h->first_id,           \
-                               h->rows_n_iter, edge2, h->d_offsets, total, d_rows, h->d_ctr,    \
-                               NBODY ? h->d_moonpos : (const double *)nullptr);                 \
-    } while (0)
-        if (h->have_bodies) NXC_LAUNCH_ROWS(false, true);
-        else if (h->have_bounce) NXC_LAUNCH_ROWS(true, false);
-        else NXC_LAUNCH_ROWS(false, false);
-#undef NXC_LAUNCH_ROWS
-        if (!rc) e = hipGetLastError();
-    }
-    if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
-    if (e == hipSuccess && !rc) {
-        h->timed = true;
-        e = hipMemcpyAsync(rows_out, d_rows, bytes, hipMemcpyDeviceToHost, h->stream);
-    }
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_rows);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
-    return NXC_OK;
-    });
+    return guarded([&]() -> int { return rows_fetch(h, rows_out, false); });
+}
+
+int nxc_rows_fetch_f32(nxc_handle *h, float *rows_out)
+{
+    return guarded([&]() -> int { return rows_fetch(h, rows_out, true); });
 }
 
 int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,

@@ -615,6 +615,14 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
 
+// save()'s 32-bit down-cast (Output.py:528-543) for rows that are about to leave the device
+__global__ void k_narrow_f32(const double *__restrict__ in, float *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (float)in[i];
+}
+
 __global__ void k_math(const unsigned char *__restrict__ blob, int which, int64_t n,
                        const double *__restrict__ in, const double *__restrict__ in2,
                        double *__restrict__ out)

@@ -26,7 +26,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
            'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
-           'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_device_bus_id',
+           'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64')
 
 
@@ -360,18 +360,22 @@ class Context:
         return dict(traj=traj, final=None if final is None else np.ascontiguousarray(final.T),
                     steps=steps)
 
-    def integrate_const_rows(self, step, n_iter, outeredge):
+    def integrate_const_rows(self, step, n_iter, outeredge, narrow=False):
         """Trajectories as Output.save() keeps them: only the records with frac > 0,
         packet-major.  Returns dict(lengths (N,) int64, rows (9, total): the 8 state columns and
-        lossfrac)."""
+        lossfrac); narrow=True delivers them as float32 (save()'s down-cast, done on the device)."""
         n = self.n_packets
         lengths = np.empty(n, dtype=np.int64)
         total = C.c_int64(0)
         self._check(self.lib.nxc_integrate_const_rows(
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             lengths.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total)))
-        rows = np.empty((9, int(total.value)))
-        self._check(self.lib.nxc_rows_fetch(self._h, _p(rows) if total.value else None))
+        rows = np.empty((9, int(total.value)), dtype=np.float32 if narrow else np.float64)
+        if narrow:
+            self._check(self.lib.nxc_rows_fetch_f32(
+                self._h, rows.ctypes.data_as(C.POINTER(C.c_float)) if total.value else None))
+        else:
+            self._check(self.lib.nxc_rows_fetch(self._h, _p(rows) if total.value else None))
         return dict(lengths=lengths, rows=rows)
 
     def integrate_const_async(self, step, n_iter, outeredge, image=True):

@@ -288,6 +288,7 @@ def test_compact_rows_equal_the_filtered_dense_trajectory(ctx, coracle, bounce):
         ctx.upload_packets(X0)
         res = ctx.integrate_const_rows(step, n_iter, 6.0)
         assert ctx.counters()['unfinished'] == 0
+        narrow = ctx.integrate_const_rows(step, n_iter, 6.0, narrow=True)      # nxc_rows_fetch_f32
     finally:
         ctx.set_bounce(None)
     frac = dense[7].T                                                            # (N, nsteps)
@@ -302,6 +303,9 @@ def test_compact_rows_equal_the_filtered_dense_trajectory(ctx, coracle, bounce):
         act = frac[:, ct-1] > 0
         lossfrac[act, ct] = (lossfrac[act, ct-1] + frac[act, ct-1]) - frac[act, ct]
     assert np.array_equal(res['rows'][8], lossfrac[live])
+    # the rows narrowed on the device = save()'s float32 down-cast of the same rows (Output.py:528-543)
+    assert narrow['rows'].dtype == np.float32 and np.array_equal(narrow['lengths'], res['lengths'])
+    assert np.array_equal(narrow['rows'], res['rows'].astype(np.float32))
     if not bounce:
         c = coracle.integrate_const(f, X0, step, n_iter, 6.0, nrec=nsteps)
         assert np.array_equal(dense, c['traj'])
