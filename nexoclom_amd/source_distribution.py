@@ -54,6 +54,20 @@ def local_frame(x, y, z):
     return _unit_rows(radial), _unit_rows(east), _unit_rows(north)
 
 
+def _unit_columns(a, b, c):
+    """(a, b, c)/|(a, b, c)| component by component.  The norm is formed like np.linalg.norm
+    forms it for the rows of an (n, 3) array -- sqrt((a*a + b*b) + c*c) -- so the columns carry
+    the bits `_unit_rows` would give, without the strided (n, 3) temporaries."""
+    length = np.sqrt((a*a + b*b) + c*c)
+    return a/length, b/length, c/length
+
+
+def local_frame_columns(x, y, z):
+    """`local_frame` as three tuples of 1-D arrays (bit-identical components)."""
+    return (_unit_columns(x, y, z), _unit_columns(y, -x, np.zeros_like(z)),
+            _unit_columns(-z*x, -z*y, x**2+y**2))
+
+
 def _ascending(first, second):
     """An angular range that runs through 2 pi is unwrapped so that it ascends."""
     return (first, second) if first <= second else (first, second + TWO_PI)
@@ -260,8 +274,8 @@ def angular_distribution(outputs):
         X0['v_east'] = np.sqrt(X0['v']**2 - X0['v_radial']**2)
         X0['v_north'] = 0
         return
-    radial, east, north = local_frame(x, y, z)
-    heading = ((level * np.cos(az))[:, np.newaxis]*north + (level * np.sin(az))[:, np.newaxis]*east
-               + up[:, np.newaxis]*radial)
-    X0['vx'], X0['vy'], X0['vz'] = (heading[:, k] * speed for k in range(3))
+    radial, east, north = local_frame_columns(x, y, z)
+    to_north, to_east = level * np.cos(az), level * np.sin(az)
+    for name, r, e, n in zip(('vx', 'vy', 'vz'), radial, east, north):
+        X0[name] = ((to_north*n + to_east*e) + up*r) * speed
     X0['altitude'], X0['azimuth'] = alt, az
