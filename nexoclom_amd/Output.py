@@ -63,7 +63,10 @@ class Output:
         self.idnum = None
         if run_model:
             self.randgen = np.random.default_rng(seed=seed)
-            assert self.inputs.geometry.type != 'geometry with time', (
+            # the parser calls it 'geometry with starttime' (input_classes.py:77), which slips past
+            # the reference's assert and dies on the missing .taa; both spellings stop here
+            assert self.inputs.geometry.type not in ('geometry with time',
+                                                     'geometry with starttime'), (
                 'Initialization with time stamp not implemented yet.')
             self.compress = compress
             npackets = int(npackets)
