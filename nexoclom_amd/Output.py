@@ -63,7 +63,7 @@ class Output:
         self.idnum = None
         if run_model:
             self.randgen = np.random.default_rng(seed=seed)
-            # the parser calls it 'geometry with starttime' (input_classes.py:77), which slips past
+            # the parser calls it 'geometry with starttime' (input_classes.py:75), which slips past
             # the reference's assert and dies on the missing .taa; both spellings stop here
             assert self.inputs.geometry.type not in ('geometry with time',
                                                      'geometry with starttime'), (
