@@ -28,6 +28,7 @@ from .atomicdata import gValue
 from .input_classes import InputError
 from .units import Quantity
 
+HOST_SAMPLER_THREADS = 4        # chunks drawn ahead of the device by the streaming image
 QUANTITIES = ('column', 'radiance', 'density', 'difrad')
 EMISSION = ('radiance', 'difrad')
 # resonance lines [Angstrom] summed when params name none (ModelResult.py:124-129)
@@ -264,35 +265,56 @@ class ModelImage(ModelResult):
         first = True
         totals = {}
         src = bounce = bodies = None
-        for k, c0, clen, a, b in chunk_plan(total, chunk, lo, hi):
-            n = b - a
-            if sampler == 'device' and not first:
-                # same inputs, next slice of the counter space: no need to rebuild the tables
-                ctx.sample_packets(n, 0 if seed is None else seed, a, **src)
-            elif sampler == 'device':     # one counter space: packet i is draw block i
-                out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
-                             sampler='device', first_index=a, materialize_x0=False)
-                src, bounce, bodies = out.source_desc(), out._bounce, out._bodies
-            else:
-                # the whole chunk is drawn (the generator is sequential), rows [a, b) are kept
-                out = Output(inputs, clen, seed=None if seed is None else seed + k,
-                             integrate=False, save=False, context=ctx)
-                bounce, bodies = out._bounce, out._bodies
-            if first:
-                ctx.set_forces(**out.forces_kwargs())
-                self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
-                first = False
-            if sampler != 'device':
-                soa = out.x0_soa()
-                ctx.upload_soa(soa if n == clen else np.ascontiguousarray(soa[:, a-c0:b-c0]))
-            ctx.set_bounce(bounce)
-            ctx.set_bodies(bodies)
-            ctx.set_first_index(a)
-            ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
-            for key, v in ctx.counters().items():
-                totals[key] = totals.get(key, 0) + v
-            self.totalsource += n * nsteps                                  # Output.py:434
-            self.npackets += n
+        plan = list(chunk_plan(total, chunk, lo, hi))
+
+        def host_chunk(k, clen):
+            # the whole chunk is drawn (the generator is sequential), rows [a, b) are kept
+            return Output(inputs, clen, seed=None if seed is None else seed + k,
+                          integrate=False, save=False, context=ctx)
+
+        # host-sampled chunks are independent generators (seed + k): the next ones are drawn by
+        # worker threads (NumPy releases the GIL) while the device integrates the current one
+        ahead, pool = {}, None
+        if sampler != 'device' and len(plan) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(len(plan), HOST_SAMPLER_THREADS))
+        try:
+            for position, (k, c0, clen, a, b) in enumerate(plan):
+                n = b - a
+                if sampler == 'device' and not first:
+                    # same inputs, next slice of the counter space: no need to rebuild the tables
+                    ctx.sample_packets(n, 0 if seed is None else seed, a, **src)
+                elif sampler == 'device':     # one counter space: packet i is draw block i
+                    out = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
+                                 sampler='device', first_index=a, materialize_x0=False)
+                    src, bounce, bodies = out.source_desc(), out._bounce, out._bodies
+                else:
+                    if pool is not None:
+                        for later in plan[position:position + HOST_SAMPLER_THREADS]:
+                            if later[0] not in ahead:
+                                ahead[later[0]] = pool.submit(host_chunk, later[0], later[2])
+                        out = ahead.pop(k).result()
+                    else:
+                        out = host_chunk(k, clen)
+                    bounce, bodies = out._bounce, out._bodies
+                if first:
+                    ctx.set_forces(**out.forces_kwargs())
+                    self._set_image(ctx, out.aplanet, out.vrplanet, downcast)   # clears the image
+                    first = False
+                if sampler != 'device':
+                    soa = out.x0_soa()
+                    ctx.upload_soa(soa if n == clen else np.ascontiguousarray(soa[:, a-c0:b-c0]))
+                ctx.set_bounce(bounce)
+                ctx.set_bodies(bodies)
+                ctx.set_first_index(a)
+                ctx.integrate_const(float(opt.step_size), n_iter, opt.outeredge, image=True)
+                for key, v in ctx.counters().items():
+                    totals[key] = totals.get(key, 0) + v
+                self.totalsource += n * nsteps                                  # Output.py:434
+                self.npackets += n
+        finally:
+            if pool is not None:
+                pool.shutdown(cancel_futures=True)
         self.counters = totals
         assert totals.get('nonfinite', 0) == 0, 'Non-finite weights'
         if first:       # an empty shard still owns a resident (zero) image for the reduce
