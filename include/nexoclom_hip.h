@@ -325,6 +325,14 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
                        const double *vy, const double *frac, const int64_t *index,
                        int64_t n_index, double *radiance, int64_t *npackets, uint8_t *included,
                        int64_t used_cap, int64_t *used_pairs, int64_t *n_used);
+/* The same for sample columns in the 32-bit form Output.save() stores (Output.py:528-543); the
+ * device widens them exactly as restore() would (Output.py:555-570). */
+int nxc_los_accumulate_f32(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
+                           int64_t P, const float *x, const float *y, const float *z,
+                           const float *vy, const float *frac, const int64_t *index,
+                           int64_t n_index, double *radiance, int64_t *npackets,
+                           uint8_t *included, int64_t used_cap, int64_t *used_pairs,
+                           int64_t *n_used);
 
 /* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
  * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other

@@ -589,6 +589,109 @@ int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
     return NXC_OK;
 }
 
+// f-1 over stored samples, 64-bit or as save() keeps them (32-bit)
+template <typename T>
+int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, int64_t P,
+                   const T *x, const T *y, const T *z, const T *vy, const T *frac,
+                   const int64_t *index, int64_t n_index, double *radiance, int64_t *npackets,
+                   uint8_t *included, int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+{
+    if (!h || !d || S < 1 || P < 0 || !sc || !radiance || !npackets ||
+        (P && (!x || !y || !z || !vy || !frac)))
+        return fail(NXC_ERR_ARG, "bad arguments");
+    if (d->n_lines < 0 || d->n_lines > NXC_MAX_LINES || d->n_ladder < 1 || !d->ladder)
+        return fail(NXC_ERR_ARG, "bad nxc_los_desc");
+    if (included && n_index < 1) return fail(NXC_ERR_ARG, "included needs n_index");
+    if (used_pairs && (used_cap < 1 || !n_used)) return fail(NXC_ERR_ARG, "used_pairs needs a capacity");
+    HIPCHK(hipSetDevice(h->device));
+
+    // LDS block: [header space | g-value tables | spectra tile]
+    std::vector<unsigned char> blob((size_t)NXC_HEADER_BYTES, 0);
+    std::memcpy(blob.data(), &h->header, sizeof(LdsHeader));      // nxc_log's table lives there
+    LosK K{};
+    K.sin_dphi = d->sin_dphi;
+    K.sin_2dphi = d->sin_2dphi;
+    K.cos_thr = d->cos_threshold;
+    K.cos_thr2_lo = d->cos_threshold * d->cos_threshold * (1.0 - 1e-9);
+    K.vrplanet = d->vrplanet;
+    K.unit_cm2 = d->unit_cm * d->unit_cm;
+    K.t0 = d->ladder[0];
+    K.log1p_s_inv = 1.0 / std::log1p(d->sin_dphi);
+    K.n_lines = d->n_lines;
+    K.n_ladder = (int)d->n_ladder;
+    for (int l = 0; l < d->n_lines; l++) {
+        PackedLut lut;
+        int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
+        if (rc) return rc;
+        K.line[l] = placed_lut(lut.desc, blob.size());
+        blob.insert(blob.end(), lut.bytes.begin(), lut.bytes.end());
+    }
+    const size_t stage_bytes = blob.size();
+    K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
+    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double);
+    if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
+
+    // device buffers: blob | sc | samples(5) | index | ladder | radiance | npackets | included | used
+    const size_t colP = (size_t)P * sizeof(T);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
+    const size_t o_blob = take(stage_bytes), o_sc = take((size_t)8 * S * 8), o_smp = take(5 * colP),
+                 o_idx = take(index ? (size_t)P * 8 : 0), o_lad = take((size_t)d->n_ladder * 8),
+                 o_rad = take((size_t)S * 8), o_np = take((size_t)S * 8),
+                 o_inc = take(included ? (size_t)n_index : 0),
+                 o_used = take(used_pairs ? (size_t)used_cap * 16 : 0), o_nu = take(8);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, off);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scratch);
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemcpyAsync(base + o_blob, blob.data(), stage_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(base + o_sc, sc, (size_t)8 * S * 8, hipMemcpyHostToDevice, st));
+    const T *cols[5] = {x, y, z, vy, frac};
+    for (int c = 0; c < 5 && P; c++)
+        HIPCHK(hipMemcpyAsync(base + o_smp + c * colP, cols[c], colP, hipMemcpyHostToDevice, st));
+    if (index && P) HIPCHK(hipMemcpyAsync(base + o_idx, index, (size_t)P * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(base + o_lad, d->ladder, (size_t)d->n_ladder * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(base + o_rad, 0, (size_t)S * 8, st));
+    HIPCHK(hipMemsetAsync(base + o_np, 0, (size_t)S * 8, st));
+    if (included) HIPCHK(hipMemsetAsync(base + o_inc, 0, (size_t)n_index, st));
+    HIPCHK(hipMemsetAsync(base + o_nu, 0, 8, st));
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), st));
+    if (P > 0) {
+        if ((rc = prep_kernel(k_los<T>, lds))) return rc;
+        const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
+        int gx = flat_grid(h, P, NXC_BLOCK);
+        if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
+        const T *smp = reinterpret_cast<const T *>(base + o_smp);
+        if ((rc = begin_timed(h))) return rc;
+        hipLaunchKernelGGL(k_los<T>, dim3(gx, tiles), dim3(NXC_BLOCK), lds, st, K, base + o_blob,
+                           (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc), P,
+                           smp, smp + P, smp + 2 * P, smp + 3 * P, smp + 4 * P,
+                           index ? reinterpret_cast<const long long *>(base + o_idx) : nullptr,
+                           reinterpret_cast<const double *>(base + o_lad),
+                           reinterpret_cast<double *>(base + o_rad),
+                           reinterpret_cast<unsigned long long *>(base + o_np),
+                           included ? base + o_inc : nullptr, (long long)used_cap,
+                           used_pairs ? reinterpret_cast<long long *>(base + o_used) : nullptr,
+                           reinterpret_cast<unsigned long long *>(base + o_nu), h->d_ctr);
+        HIPCHK(hipGetLastError());
+        if ((rc = end_timed(h))) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(radiance, base + o_rad, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(npackets, base + o_np, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    if (included) HIPCHK(hipMemcpyAsync(included, base + o_inc, (size_t)n_index, hipMemcpyDeviceToHost, st));
+    unsigned long long nu = 0;
+    HIPCHK(hipMemcpyAsync(&nu, base + o_nu, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n_used) *n_used = (int64_t)nu;
+    if (used_pairs) {
+        const size_t got = (size_t)std::min<unsigned long long>(nu, (unsigned long long)used_cap);
+        HIPCHK(hipMemcpy(used_pairs, base + o_used, got * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(used_pairs + used_cap, base + o_used + (size_t)used_cap * 8, got * 8,
+                         hipMemcpyDeviceToHost));
+    }
+    return NXC_OK;
+}
+
 // a-6..a-8 over stored samples, 64-bit or as save() keeps them (32-bit)
 template <typename T>
 int image_accumulate(nxc_handle *h, int64_t p, const T *x, const T *y, const T *z, const T *vy,
@@ -1403,100 +1506,20 @@ int nxc_los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const do
                        int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
 {
     return guarded([&]() -> int {
-    if (!h || !d || S < 1 || P < 0 || !sc || !radiance || !npackets ||
-        (P && (!x || !y || !z || !vy || !frac)))
-        return fail(NXC_ERR_ARG, "bad arguments");
-    if (d->n_lines < 0 || d->n_lines > NXC_MAX_LINES || d->n_ladder < 1 || !d->ladder)
-        return fail(NXC_ERR_ARG, "bad nxc_los_desc");
-    if (included && n_index < 1) return fail(NXC_ERR_ARG, "included needs n_index");
-    if (used_pairs && (used_cap < 1 || !n_used)) return fail(NXC_ERR_ARG, "used_pairs needs a capacity");
-    HIPCHK(hipSetDevice(h->device));
+        return los_accumulate(h, d, S, sc, P, x, y, z, vy, frac, index, n_index, radiance, npackets,
+                              included, used_cap, used_pairs, n_used);
+    });
+}
 
-    // LDS block: [header space | g-value tables | spectra tile]
-    std::vector<unsigned char> blob((size_t)NXC_HEADER_BYTES, 0);
-    std::memcpy(blob.data(), &h->header, sizeof(LdsHeader));      // nxc_log's table lives there
-    LosK K{};
-    K.sin_dphi = d->sin_dphi;
-    K.sin_2dphi = d->sin_2dphi;
-    K.cos_thr = d->cos_threshold;
-    K.cos_thr2_lo = d->cos_threshold * d->cos_threshold * (1.0 - 1e-9);
-    K.vrplanet = d->vrplanet;
-    K.unit_cm2 = d->unit_cm * d->unit_cm;
-    K.t0 = d->ladder[0];
-    K.log1p_s_inv = 1.0 / std::log1p(d->sin_dphi);
-    K.n_lines = d->n_lines;
-    K.n_ladder = (int)d->n_ladder;
-    for (int l = 0; l < d->n_lines; l++) {
-        PackedLut lut;
-        int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
-        if (rc) return rc;
-        K.line[l] = placed_lut(lut.desc, blob.size());
-        blob.insert(blob.end(), lut.bytes.begin(), lut.bytes.end());
-    }
-    const size_t stage_bytes = blob.size();
-    K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
-    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double);
-    if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
-
-    // device buffers: blob | sc | samples(5) | index | ladder | radiance | npackets | included | used
-    const size_t colP = (size_t)P * sizeof(double);
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
-    const size_t o_blob = take(stage_bytes), o_sc = take((size_t)8 * S * 8), o_smp = take(5 * colP),
-                 o_idx = take(index ? (size_t)P * 8 : 0), o_lad = take((size_t)d->n_ladder * 8),
-                 o_rad = take((size_t)S * 8), o_np = take((size_t)S * 8),
-                 o_inc = take(included ? (size_t)n_index : 0),
-                 o_used = take(used_pairs ? (size_t)used_cap * 16 : 0), o_nu = take(8);
-    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, off);
-    if (rc) return rc;
-    unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scratch);
-    hipStream_t st = h->stream;
-    HIPCHK(hipMemcpyAsync(base + o_blob, blob.data(), stage_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(base + o_sc, sc, (size_t)8 * S * 8, hipMemcpyHostToDevice, st));
-    const double *cols[5] = {x, y, z, vy, frac};
-    for (int c = 0; c < 5 && P; c++)
-        HIPCHK(hipMemcpyAsync(base + o_smp + c * colP, cols[c], colP, hipMemcpyHostToDevice, st));
-    if (index && P) HIPCHK(hipMemcpyAsync(base + o_idx, index, (size_t)P * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(base + o_lad, d->ladder, (size_t)d->n_ladder * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(base + o_rad, 0, (size_t)S * 8, st));
-    HIPCHK(hipMemsetAsync(base + o_np, 0, (size_t)S * 8, st));
-    if (included) HIPCHK(hipMemsetAsync(base + o_inc, 0, (size_t)n_index, st));
-    HIPCHK(hipMemsetAsync(base + o_nu, 0, 8, st));
-    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), st));
-    if (P > 0) {
-        if ((rc = prep_kernel(k_los, lds))) return rc;
-        const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
-        int gx = flat_grid(h, P, NXC_BLOCK);
-        if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
-        const double *smp = reinterpret_cast<const double *>(base + o_smp);
-        if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL(k_los, dim3(gx, tiles), dim3(NXC_BLOCK), lds, st, K, base + o_blob,
-                           (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc), P,
-                           smp, smp + P, smp + 2 * P, smp + 3 * P, smp + 4 * P,
-                           index ? reinterpret_cast<const long long *>(base + o_idx) : nullptr,
-                           reinterpret_cast<const double *>(base + o_lad),
-                           reinterpret_cast<double *>(base + o_rad),
-                           reinterpret_cast<unsigned long long *>(base + o_np),
-                           included ? base + o_inc : nullptr, (long long)used_cap,
-                           used_pairs ? reinterpret_cast<long long *>(base + o_used) : nullptr,
-                           reinterpret_cast<unsigned long long *>(base + o_nu), h->d_ctr);
-        HIPCHK(hipGetLastError());
-        if ((rc = end_timed(h))) return rc;
-    }
-    HIPCHK(hipMemcpyAsync(radiance, base + o_rad, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(npackets, base + o_np, (size_t)S * 8, hipMemcpyDeviceToHost, st));
-    if (included) HIPCHK(hipMemcpyAsync(included, base + o_inc, (size_t)n_index, hipMemcpyDeviceToHost, st));
-    unsigned long long nu = 0;
-    HIPCHK(hipMemcpyAsync(&nu, base + o_nu, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (n_used) *n_used = (int64_t)nu;
-    if (used_pairs) {
-        const size_t got = (size_t)std::min<unsigned long long>(nu, (unsigned long long)used_cap);
-        HIPCHK(hipMemcpy(used_pairs, base + o_used, got * 8, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(used_pairs + used_cap, base + o_used + (size_t)used_cap * 8, got * 8,
-                         hipMemcpyDeviceToHost));
-    }
-    return NXC_OK;
+int nxc_los_accumulate_f32(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
+                           int64_t P, const float *x, const float *y, const float *z,
+                           const float *vy, const float *frac, const int64_t *index,
+                           int64_t n_index, double *radiance, int64_t *npackets, uint8_t *included,
+                           int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+{
+    return guarded([&]() -> int {
+        return los_accumulate(h, d, S, sc, P, x, y, z, vy, frac, index, n_index, radiance, npackets,
+                              included, used_cap, used_pairs, n_used);
     });
 }
 

@@ -661,11 +661,13 @@ struct LosK {
 
 constexpr int NXC_LOS_TILE = 128;  // spectra per workgroup tile (8 doubles each)
 
+// T: double, or float for samples as Output.save() stores them (widened exactly, like restore())
+template <typename T>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
-      const double *__restrict__ sc, int64_t P, const double *__restrict__ x,
-      const double *__restrict__ y, const double *__restrict__ z, const double *__restrict__ vy,
-      const double *__restrict__ frac, const long long *__restrict__ index,
+      const double *__restrict__ sc, int64_t P, const T *__restrict__ x,
+      const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ vy,
+      const T *__restrict__ frac, const long long *__restrict__ index,
       const double *__restrict__ ladder, double *__restrict__ radiance,
       unsigned long long *__restrict__ npackets, unsigned char *__restrict__ included,
       long long used_cap, long long *__restrict__ used_pairs,

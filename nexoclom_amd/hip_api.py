@@ -24,7 +24,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_integrate_const_async', 'nxc_integrate_var', 'nxc_image_accumulate',
            'nxc_image_accumulate_f32',
            'nxc_comm_unique_id', 'nxc_comm_init', 'nxc_comm_destroy', 'nxc_image_allreduce',
-           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate', 'nxc_packets_sample',
+           'nxc_allreduce_max_f64', 'nxc_barrier', 'nxc_math_batch', 'nxc_los_accumulate',
+           'nxc_los_accumulate_f32', 'nxc_packets_sample',
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64')
@@ -424,8 +425,17 @@ class Context:
         d.n_ladder, d.ladder = len(lad), _p(lad)
         sc = _f64(sc)
         S = sc.shape[1]
-        x, y, z, vy, frac = map(_f64, (x, y, z, vy, frac))
-        P = len(x)
+        cols = (x, y, z, vy, frac)
+        narrow = all(getattr(c, 'dtype', None) == np.float32 for c in cols)
+        if narrow:          # stored float32 samples go over as they are; the device widens them
+            cols = [np.ascontiguousarray(c) for c in cols]
+            ptrs = [c.ctypes.data_as(C.POINTER(C.c_float)) for c in cols]
+            entry = self.lib.nxc_los_accumulate_f32
+        else:
+            cols = [_f64(c) for c in cols]
+            ptrs = [_p(c) for c in cols]
+            entry = self.lib.nxc_los_accumulate
+        P = len(cols[0])
         radiance = np.zeros(S)
         npackets = np.zeros(S, dtype=np.int64)
         idx = None if index is None else np.ascontiguousarray(index, dtype=np.int64)
@@ -433,9 +443,9 @@ class Context:
         used = np.zeros((2, used_cap), dtype=np.int64) if used_cap else None
         n_used = C.c_int64(0)
         i64p = C.POINTER(C.c_int64)
-        self._check(self.lib.nxc_los_accumulate(
-            self._h, C.byref(d), C.c_int64(S), _p(sc), C.c_int64(P), _p(x), _p(y), _p(z), _p(vy),
-            _p(frac), idx.ctypes.data_as(i64p) if idx is not None else None, C.c_int64(n_index),
+        self._check(entry(
+            self._h, C.byref(d), C.c_int64(S), _p(sc), C.c_int64(P), *ptrs,
+            idx.ctypes.data_as(i64p) if idx is not None else None, C.c_int64(n_index),
             _p(radiance), npackets.ctypes.data_as(i64p),
             included.ctypes.data_as(C.POINTER(C.c_uint8)) if included is not None else None,
             C.c_int64(used_cap), used.ctypes.data_as(i64p) if used is not None else None,

@@ -201,8 +201,14 @@ def test_los_used_pairs_and_tiles(ctx):
     dphi = np.radians(1.0)
     los = LOSResult(sc, inputs, dphi=dphi, context=ctx)
     out = inputs._catalogue[0]
+    assert out.X.x.dtype == np.float32            # as saved: goes through nxc_los_accumulate_f32
     it = los.compute_iteration(out, sc, used_cap=200000)
     X = Output.restore(out).X
+    assert out.X.x.dtype == np.float64            # restored: nxc_los_accumulate, same answer
+    again = los.compute_iteration(out, sc, used_cap=200000)
+    assert np.array_equal(again['npackets'].values, it['npackets'].values)
+    assert np.array_equal(again['included'], it['included']) and again['n_used'] == it['n_used']
+    np.testing.assert_allclose(again['radiance'].values, it['radiance'].values, rtol=1e-12, atol=0)
     smp = dict(x=X.x.values, y=X.y.values, z=X.z.values, vy=X.vy.values, frac=X.frac.values,
                Index=X.Index.values)
     scd = {k: sc.data[k].values for k in sc.data.columns}
