@@ -18,14 +18,27 @@ src = os.path.join(ROOT, 'gpurun_out', f'prof_{tag}')
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 
-for f in glob.glob(os.path.join(src, 'trace', '**', '*_kernel_stats.csv'), recursive=True):
+
+
+def newest(pattern):
+    """One file per pass directory: the most recent run's (gpurun merges every call's files into
+    the same local directory, so a tag profiled twice holds both runs)."""
+    by_pass = {}
+    for f in glob.glob(pattern, recursive=True):
+        key = os.path.relpath(f, src).split(os.sep)[0]
+        if key not in by_pass or os.path.getmtime(f) > os.path.getmtime(by_pass[key]):
+            by_pass[key] = f
+    return list(by_pass.values())
+
+
+for f in newest(os.path.join(src, 'trace', '**', '*_kernel_stats.csv')):
     shutil.copy(f, os.path.join(dst, f'{tag}_kernel_stats.csv'))
 bl = os.path.join(src, 'bench_line.json')
 if os.path.exists(bl):
     shutil.copy(bl, os.path.join(dst, f'{tag}_bench_line.json'))
 
 pmc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(src, '*', '**', '*_counter_collection.csv'), recursive=True):
+for f in newest(os.path.join(src, '*', '**', '*_counter_collection.csv')):
     for row in csv.DictReader(open(f)):
         name = row['Kernel_Name'].split('(')[0]
         pmc[name][row['Counter_Name']].append(float(row['Counter_Value']))
