@@ -318,3 +318,58 @@ def test_tables_match_the_text_file_restatement():
         rr, vv = planet_dist(m, taa)
         assert float(rr) == r and float(vv) == vr
     assert m.GM.value/(m.radius.value*1e3)**3 == float(g['mercury_GM_R3'])
+
+
+def test_los_geometry_shared_ladder_equals_per_spectrum_ladders():
+    """compute_iteration.py:157-167 builds one geometric ladder per spectrum; los_geometry builds
+    the longest once and finds each spectrum's length by search.  Same lengths, same rungs, for
+    lines that leave the sphere, start outside it and never meet it (NaN root)."""
+    from nexoclom_amd.LOSResult import SpacecraftData, ladder_to, los_geometry
+    rng = np.random.default_rng(2)
+    S = 200
+    pos = rng.normal(size=(S, 3))*rng.uniform(0.5, 60, (S, 1))
+    look = rng.normal(size=(S, 3))
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    sc = SpacecraftData(*pos.T, *look.T)
+    dphi = np.radians(1.0)
+    for outeredge in (3., 25., 100.):
+        lengths, longest = [], []
+        for x_sc, bore in zip(pos, look):
+            b = 2*np.sum(x_sc*bore)
+            c = np.linalg.norm(x_sc)**2 - outeredge**2
+            with np.errstate(invalid='ignore'):
+                far = (-b + np.sqrt(b**2 - 4*1*c))/2
+            rungs = ladder_to(far, np.sin(dphi), np.sin(dphi))
+            lengths.append(len(rungs))
+            longest = rungs if len(rungs) > len(longest) else longest
+        _, got_lengths, got_ladder = los_geometry(sc.data, outeredge, dphi)
+        assert np.array_equal(got_lengths, lengths)
+        assert np.array_equal(got_ladder, np.array(longest))
+        assert min(lengths) == 1 and max(lengths) > 100          # the NaN / inside cases occur
+
+
+def test_output_frames_are_retyped_like_save_and_restore(tmp_path):
+    """save()'s 32-bit down-cast and restore()'s up-cast (Output.py:528-543, 555-570) on whole
+    frames, and the five image columns read back from an .npz without restoring the rest."""
+    import pandas as pd
+    from nexoclom_amd.Output import NARROW, WIDE, Output
+    n = 1000
+    rng = np.random.default_rng(4)
+    frame = pd.DataFrame({'Index': np.arange(n, dtype=np.int64), 'x': rng.normal(size=n),
+                          'frac': rng.random(n), 'flag': np.arange(n) % 2 == 0},
+                         index=np.arange(n)*7)
+    narrow = Output._recast(frame, NARROW)
+    assert [str(t) for t in narrow.dtypes] == ['int32', 'float32', 'float32', 'bool']
+    assert np.array_equal(narrow.index, frame.index)
+    assert np.array_equal(narrow.x.values, frame.x.values.astype(np.float32))
+    wide = Output.upcast(narrow)
+    assert [str(t) for t in wide.dtypes] == ['int64', 'float64', 'float64', 'bool']
+    assert np.array_equal(wide.x.values, frame.x.values.astype(np.float32).astype(np.float64))
+    assert Output._recast(wide, NARROW) is not wide and Output._recast(wide, WIDE) is wide
+    cols = {f'X.{c}': rng.normal(size=50).astype(np.float32) for c in ('x', 'y', 'z', 'vy', 'frac', 'vx')}
+    path = str(tmp_path / 'out.npz')
+    np.savez(path, aplanet=0.35, vrplanet_kms=9.7, **cols)
+    samples, aplanet, vr = Output.image_columns(path)
+    assert (aplanet, vr) == (0.35, 9.7) and len(samples) == 5
+    for got, c in zip(samples, Output.IMAGE_COLS):
+        assert got.dtype == np.float32 and np.array_equal(got, cols['X.' + c])
