@@ -55,31 +55,40 @@ typedef LutDesc LutView;
 // its base so that every access is visibly an LDS (ds_read) access to the compiler.
 extern __shared__ __align__(32) unsigned char nxc_lds[];
 
+// Reads by absolute LDS address.  The dynamic block is the only LDS these kernels use, so it
+// starts at LDS address 0 (stage_tables checks) and a byte offset IS the address: going through
+// the nxc_lds symbol instead makes the compiler add its (zero) address to every computed offset,
+// one wasted VALU instruction per table read.
+#define NXC_LDS_AS __attribute__((address_space(3)))
+typedef double nxc_v2d __attribute__((ext_vector_type(2)));
+
 NXC_DEV double lds_f64(int byte_off)
 {
-    return *reinterpret_cast<const double *>(nxc_lds + byte_off);
+    return *(const NXC_LDS_AS double *)(unsigned)byte_off;
 }
 NXC_DEV int lds_u16(int byte_off)
 {
-    return *reinterpret_cast<const unsigned short *>(nxc_lds + byte_off);
+    return *(const NXC_LDS_AS unsigned short *)(unsigned)byte_off;
 }
 
 NXC_DEV double2 lds_f64x2(int byte_off)
 {
-    return *reinterpret_cast<const double2 *>(nxc_lds + byte_off);
+    const nxc_v2d v = *(const NXC_LDS_AS nxc_v2d *)(unsigned)byte_off;
+    return make_double2(v.x, v.y);
 }
 
 NXC_DEV const LutView &lut_view(const LutDesc &d) { return d; }
 
-// The cell of x: v_cvt_i32_f64 saturates (and turns NaN into 0), which the clamp relies on; as
-// the bare instruction because a C++ double -> int cast of an out-of-range value is undefined.
+// The cell of x: v_cvt_u32_f64 saturates (negative -> 0, too large -> UINT_MAX) and turns NaN into
+// 0, which leaves one unsigned minimum to clamp; as the bare instruction because a C++
+// double -> unsigned cast of an out-of-range value is undefined.
 NXC_DEV int lut_cell(const LutView &t, double x)
 {
     const double s = (x - t.xbase) * t.inv_w;
-    int c;
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(c) : "v"(s));
-    c = c < 0 ? 0 : c;
-    return c > t.top ? t.top : c;
+    unsigned c;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(c) : "v"(s));
+    const unsigned top = (unsigned)t.top;
+    return (int)(c > top ? top : c);
 }
 
 // A lookup in two halves, so that a caller can put independent arithmetic between the LDS reads
@@ -101,7 +110,9 @@ NXC_DEV void lut_probe_cell(const LutView &t, double x, LutProbe &p)
 
 NXC_DEV void lut_probe_rows(const LutView &t, LutProbe &p)
 {
-    const int ra = t.rec + 16 * p.r, rb = ra + (t.fs - t.rec);
+    // each address as (launch constant) + 16 r: one v_lshl_add_u32 apiece (deriving the second
+    // from the first costs the compiler an extra add for the LDS block's own base)
+    const int ra = t.rec + 16 * p.r, rb = t.fs + 16 * p.r;
     p.a0 = lds_f64x2(ra); p.a1 = lds_f64x2(ra + 16);
     p.b0 = lds_f64x2(rb); p.b1 = lds_f64x2(rb + 16);
 }

@@ -64,6 +64,10 @@ constexpr int NXC_WAVE_LDS_BYTES = NXC_WAVE_STAGE_BYTES + NXC_IMGQ_BYTES;
 // derived per-launch constants of the header.
 NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
 {
+    // lds_f64 & co. address the block absolutely: it must start at LDS address 0 (true as long as
+    // no kernel that uses it declares static __shared__ data; a link-time constant, so the test
+    // costs nothing)
+    if ((unsigned)(size_t)(NXC_LDS_AS unsigned char *)nxc_lds != 0u) __builtin_trap();
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(blob);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(nxc_lds);
     const int64_t words = bytes >> 3;
