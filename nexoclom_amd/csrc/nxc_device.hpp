@@ -480,13 +480,13 @@ NXC_DEV double nxc_log(double x)
     const double hi = w + r;
     const double lo = ((w - hi) + r) + __builtin_fma(kd, LN2_LO, lclo);
     double p = -0x1.999999999999ap-4;                        // -1/10
-    p = __builtin_fma(p, r, 0x1.c71c71c71c71cp-4);           //  1/9
-    p = __builtin_fma(p, r, -0x1.0p-3);                      // -1/8
-    p = __builtin_fma(p, r, 0x1.2492492492492p-3);           //  1/7
-    p = __builtin_fma(p, r, -0x1.5555555555555p-3);          // -1/6
-    p = __builtin_fma(p, r, 0x1.999999999999ap-3);           //  1/5
-    p = __builtin_fma(p, r, -0x1.0p-2);                      // -1/4
-    p = __builtin_fma(p, r, 0x1.5555555555555p-2);           //  1/3
+    p = __builtin_fma(p, r, nxc_sconst(0x1.c71c71c71c71cp-4));           //  1/9
+    p = __builtin_fma(p, r, nxc_sconst(-0x1.0p-3));                      // -1/8
+    p = __builtin_fma(p, r, nxc_sconst(0x1.2492492492492p-3));           //  1/7
+    p = __builtin_fma(p, r, nxc_sconst(-0x1.5555555555555p-3));          // -1/6
+    p = __builtin_fma(p, r, nxc_sconst(0x1.999999999999ap-3));           //  1/5
+    p = __builtin_fma(p, r, nxc_sconst(-0x1.0p-2));                      // -1/4
+    p = __builtin_fma(p, r, nxc_sconst(0x1.5555555555555p-2));           //  1/3
     return __builtin_fma(r * r, __builtin_fma(r, p, -0.5), lo) + hi;
 }
 NXC_DEV LdsHeader &lds_header_rw()

@@ -123,6 +123,15 @@ NXC_DEV double nxc_cube(double r)
 // 0.27).  The C oracle carries the same operations in the same order (the checker under oracle/c);
 // round 1 used fdlibm's rational form, whose division cost 11 of the routine's 62 issue slots --
 // this one takes 21.
+// A polynomial coefficient handed to v_fma_f64 from scalar registers.  Left alone, the compiler
+// loads each coefficient into a vector register pair (two v_mov_b32, VALU issue slots) to use it as
+// v_fmac_f64's accumulator; this costs two s_mov_b32 on the scalar unit instead, which has room.
+NXC_DEV double nxc_sconst(double c)
+{
+    asm("" : "+s"(c));
+    return c;
+}
+
 NXC_DEV double nxc_exp(double x)
 {
     constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
@@ -147,10 +156,11 @@ NXC_DEV double nxc_exp(double x)
     const double hi = __builtin_fma(-kd, LN2_HI, x);
     const double r = __builtin_fma(-kd, LN2_LO, hi);
     double q = C13;
-    q = __builtin_fma(q, r, C12); q = __builtin_fma(q, r, C11); q = __builtin_fma(q, r, C10);
-    q = __builtin_fma(q, r, C9);  q = __builtin_fma(q, r, C8);  q = __builtin_fma(q, r, C7);
-    q = __builtin_fma(q, r, C6);  q = __builtin_fma(q, r, C5);  q = __builtin_fma(q, r, C4);
-    q = __builtin_fma(q, r, C3);  q = __builtin_fma(q, r, C2);
+#define NXC_HORNER(C) q = __builtin_fma(q, r, nxc_sconst(C))
+    NXC_HORNER(C12); NXC_HORNER(C11); NXC_HORNER(C10); NXC_HORNER(C9); NXC_HORNER(C8);
+    NXC_HORNER(C7);  NXC_HORNER(C6);  NXC_HORNER(C5);  NXC_HORNER(C4); NXC_HORNER(C3);
+    NXC_HORNER(C2);
+#undef NXC_HORNER
     const double y = 1.0 + __builtin_fma(r * r, q, r);
     if (k >= -1021)
         return __longlong_as_double(__double_as_longlong(y) + ((long long)k << 52));
