@@ -428,6 +428,25 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                     rk5_step<false, true, FULL>(F, T, s, 0.0, lds_header().W, d);
                     apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + id), nbounce);
                 }
+#ifdef NXC_PROBE_VMOV      /* what binds the loop? N independent cheap / fp64 instructions per trip */
+                {
+                    int junk;
+#pragma unroll
+                    for (int j = 0; j < NXC_PROBE_VMOV; j++) asm volatile("v_mov_b32 %0, 0x12345" : "=v"(junk));
+                }
+#endif
+#ifdef NXC_PROBE_FMA
+                {
+                    double j0 = s[1], j1 = s[2], j2 = s[3], j3 = s[4];
+#pragma unroll
+                    for (int j = 0; j < NXC_PROBE_FMA / 4; j++) {
+                        asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(j0));
+                        asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(j1));
+                        asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(j2));
+                        asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(j3));
+                    }
+                }
+#endif
                 k++; my_steps++;
             }
             NXC_STAMP(1);                              // step + fate
