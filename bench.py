@@ -49,8 +49,8 @@ SEED = 1234
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=3)
-    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=2)
     p.add_argument('--packets', type=int, default=None,
                    help='packets per GPU (default 1e7 for both drivers)')
     p.add_argument('--dims', type=int, default=512)
