@@ -1,5 +1,7 @@
 """Randomised differential test: HIP (C ABI) vs C oracle over random force / step / image
 configurations.  Every state column, step count and packet count must match bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,7 +35,7 @@ def _random_case(rng):
     return f, step, endtime, outeredge, quantity, im, bool(rng.random() < 0.5)
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(int(os.environ.get('NXC_FUZZ_SEEDS', '16'))))   # soak: more
 def test_random_configuration_parity(ctx, coracle, seed):
     rng = np.random.default_rng(1000 + seed)
     f, step, endtime, outeredge, quantity, im, downcast = _random_case(rng)
