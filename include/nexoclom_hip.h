@@ -10,9 +10,12 @@
  *   nxc_rk5_step           rk5(output, X0, h)                     particle_tracking/rk5.py:21-54
  *   nxc_integrate_const    Output.constant_step_size_driver()     particle_tracking/Output.py:368-455
  *                          (+ optionally fused ModelImage.create_image of every stored step)
- *   nxc_integrate_const_rows / nxc_rows_fetch
- *                          the same driver followed by save()'s   particle_tracking/Output.py:523-524
- *                          frac > 0 row filter
+ *   nxc_integrate_const_rows / nxc_rows_fetch / nxc_rows_build
+ *                          the same driver followed by save()'s   particle_tracking/Output.py:523-543
+ *                          frac > 0 row filter and 32-bit cast;
+ *                          the rows can stay on the device for
+ *                          nxc_image_accumulate_rows /
+ *                          nxc_los_accumulate_rows
  *   nxc_integrate_var      Output.variable_step_size_driver()     particle_tracking/Output.py:221-366
  *   nxc_image_accumulate   ModelImage.create_image()              data_simulation/ModelImage.py:229-274
  *                          + ModelResult.packet_weighting()       data_simulation/ModelResult.py:140-170
@@ -45,7 +48,8 @@
 extern "C" {
 #endif
 
-#define NXC_ABI_VERSION 1
+/* 2: nxc_source_desc grew (tabulated speeds, surface maps, generator), resident row stores */
+#define NXC_ABI_VERSION 2
 #define NXC_MAX_LINES 4
 
 typedef enum {
@@ -248,8 +252,9 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
  *                           nrec must be >= n_iter+1 when given.
  *   final_out (nullable)  : host [8][n], state at the packet's last processed iteration.
  *   steps_out (nullable)  : host int64[n], iterations the packet was active.
- * With traj_out == NULL the kernel is the persistent lane-refill integrator (no trajectory is
- * ever materialised); with traj_out it is the lock-step kernel that streams records to HBM. */
+ * The kernel is always the persistent lane-refill integrator.  With traj_out == NULL no trajectory
+ * is ever materialised; with traj_out a second pass of the same kernel writes the live records
+ * (see nxc_integrate_const_rows) and a layout kernel expands them into the dense array. */
 #define NXC_RUN_IMAGE 1u
 int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                         uint32_t flags, double *traj_out, int64_t nrec, double *final_out,
@@ -261,12 +266,13 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
  * (typically > 90 % of it) is never materialised or transferred.
  *   nxc_integrate_const_rows : pass 1 (persistent kernel) counts the live records per packet;
  *                              lengths_out int64[n] (nullable), *total_out = their sum.
- *   nxc_rows_fetch           : pass 2 (lock-step kernel) re-integrates and writes rows_out, host
- *                              [9][total]: the 8 state columns and lossfrac accumulated as
- *                              (lossfrac + frac_before) - frac_after per step (Output.py:420-421),
- *                              starting from 0 (the reference's starts from uninitialised memory,
- *                              Output.py:378).  Must follow nxc_integrate_const_rows on the same
- *                              resident packets. */
+ *   nxc_rows_fetch           : pass 2 (the same persistent kernel, now writing: a lane owns its
+ *                              packet for life, so record k goes to row offset[packet] + k)
+ *                              re-integrates and delivers rows_out, host [9][total]: the 8 state
+ *                              columns and lossfrac accumulated as (lossfrac + frac_before) -
+ *                              frac_after per step (Output.py:420-421), starting from 0 (the
+ *                              reference's starts from uninitialised memory, Output.py:378).  Must
+ *                              follow nxc_integrate_const_rows on the same resident packets. */
 int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                              int64_t *lengths_out, int64_t *total_out);
 int nxc_rows_fetch(nxc_handle *h, double *rows_out);
@@ -274,6 +280,27 @@ int nxc_rows_fetch(nxc_handle *h, double *rows_out);
  * (Output.py:528-543, which every reference Output ends in, Output.py:202) makes of them, at half
  * the device-to-host bytes. */
 int nxc_rows_fetch_f32(nxc_handle *h, float *rows_out);
+/* The same rows kept ON THE DEVICE (pass 2 of the protocol above, in place of nxc_rows_fetch): an
+ * nxc_rows store holds the nine columns [9][total] plus the packet-index column (row -> number of
+ * its packet in the resident set: the reference's X.Index, Output.py:438), as float32 / int32
+ * when narrow != 0 (what save() stores, Output.py:528-543) or float64 / int64.  A store outlives
+ * the packets it was built from; it is what the reference's per-Output file is to
+ * ModelImage / LOSResult (ModelImage.py:85-98, LOSResult.py:264-266), minus the disk and the
+ * host.  Stores are freed explicitly; a handle may own any number of them.
+ *   nxc_rows_download          rows [first, first + count) -> cols_out host [9][count] (nullable)
+ *                              and index_out host [count] (nullable), in the store's types
+ *   nxc_image_accumulate_rows  create_image over those rows (columns x, y, z, vy, frac), as
+ *                              nxc_image_accumulate[_f32] without the host round trip
+ *   nxc_los_accumulate_rows    compute_iteration over those rows, as nxc_los_accumulate[_f32];
+ *                              index_shift is subtracted from the store's index column (the first
+ *                              packet of the Output the rows belong to) before `included` is set */
+typedef struct nxc_rows nxc_rows;
+int nxc_rows_build(nxc_handle *h, int narrow, nxc_rows **out);
+int nxc_rows_info(const nxc_rows *r, int64_t *total, int32_t *is_f32);
+int nxc_rows_download(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count,
+                      void *cols_out, void *index_out);
+int nxc_rows_free(nxc_handle *h, nxc_rows *r);
+int nxc_image_accumulate_rows(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count);
 /* Same launch without any host transfer or synchronisation (bench / pipelining). */
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags);
@@ -333,6 +360,12 @@ int nxc_los_accumulate_f32(nxc_handle *h, const nxc_los_desc *d, int64_t S, cons
                            int64_t n_index, double *radiance, int64_t *npackets,
                            uint8_t *included, int64_t used_cap, int64_t *used_pairs,
                            int64_t *n_used);
+
+int nxc_los_accumulate_rows(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
+                            const nxc_rows *r, int64_t first, int64_t count, int64_t index_shift,
+                            int64_t n_index, double *radiance, int64_t *npackets,
+                            uint8_t *included, int64_t used_cap, int64_t *used_pairs,
+                            int64_t *n_used);
 
 /* ---- a-9 / multi-GPU: sum of the per-GPU image pairs over RCCL ---------------------------------
  * One process per GPU.  Rank 0 calls nxc_comm_unique_id and hands the 128 bytes to the other

@@ -231,6 +231,16 @@ StepW make_stepw(double h)
 
 }  // namespace
 
+// Device-resident compact trajectory rows (nxc_rows_build): nine value columns [9][total] and the
+// packet-index column, as float32/int32 (what save() stores, Output.py:528-543) or float64/int64.
+struct nxc_rows {
+    int device = 0;
+    bool f32 = false;
+    long long total = 0;
+    void *d_cols = nullptr;
+    void *d_index = nullptr;
+};
+
 struct nxc_handle {
     int device = 0;
     int n_cu = 0;
@@ -274,6 +284,8 @@ struct nxc_handle {
     DevCounters *d_ctr = nullptr;
     double *d_scratch = nullptr;     // final states / generic device scratch
     size_t scratch_cap = 0;
+    unsigned char *d_samples = nullptr;   // host sample columns on their way to k_image / k_los
+    size_t samples_cap = 0;
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
 
@@ -367,15 +379,25 @@ int prep_kernel(K kernel, size_t lds_bytes)
     return NXC_OK;
 }
 
+// Grid of a persistent kernel: one resident block per CU slot.  When there are fewer packets than
+// lanes (one reference-sized chunk of 80 467 packets against 196 608 lanes), the packets are
+// spread over ALL CUs with fewer waves per block instead of filling a few CUs three waves deep: a
+// packet's steps run one after the other, and a wave that has its SIMD to itself takes them
+// faster.  *block comes back as the number of threads to launch per block (a multiple of 64).
 template <class K>
-int persistent_grid(nxc_handle *h, K kernel, int block, size_t lds_bytes, int64_t n, int *grid)
+int persistent_grid(nxc_handle *h, K kernel, int *block, size_t lds_bytes, int64_t n, int *grid)
 {
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds_bytes));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, *block, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     int64_t g = (int64_t)h->n_cu * per_cu;
-    const int64_t need = (n + block - 1) / block;
-    if (g > need) g = need;
+    const int64_t waves = (n + 63) / 64;
+    if (waves < g * (*block / 64)) {
+        int64_t per_block = (waves + g - 1) / g;
+        if (per_block < 1) per_block = 1;
+        *block = (int)per_block * 64;
+        g = (waves + per_block - 1) / per_block;
+    }
     if (g < 1) g = 1;
     *grid = (int)g;
     return NXC_OK;
@@ -457,16 +479,17 @@ template <bool IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false>
 int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
                  double *d_final, long long *d_steps)
 {
-    int grid = 1, rc;
+    int grid = 1, block = BLOCK_PERSIST, rc;
     auto kernel = k_const_fused<IMAGE, BOUNCE, FULL, NBODY>;
     if ((rc = prep_kernel(kernel, lds))) return rc;
-    if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, h->n_packets, &grid))) return rc;
+    if ((rc = persistent_grid(h, kernel, &block, lds, h->n_packets, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
                        (int64_t)tables, h->n_packets, h->have_order ? h->d_queue : h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
                        edge2, d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr, h->d_ctr,
-                       NBODY ? h->d_moonpos : (const double *)nullptr);
+                       NBODY ? h->d_moonpos : (const double *)nullptr, (const long long *)nullptr,
+                       (double *)nullptr);
     HIPCHK(hipGetLastError());
     return end_timed(h);
 }
@@ -502,40 +525,86 @@ int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, b
                           : launch_fused<false, false>(h, tables, lds, n_iter, edge2, d_final, d_steps);
 }
 
-template <bool IMAGE, bool BOUNCE, bool NBODY = false>
-int launch_traj(nxc_handle *h, size_t lds, int64_t n_iter, double edge2, double *d_traj,
-                int64_t nrec, double *d_final, long long *d_steps)
+size_t persist_lds_rows(size_t table_bytes)
+{
+    return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES_ROWS;
+}
+
+template <bool BOUNCE, bool FULL, bool NBODY>
+int launch_rows(nxc_handle *h, int64_t n_iter, double edge2, double *d_rec)
+{
+    int grid = 1, block = BLOCK_PERSIST, rc;
+    auto kernel = k_const_fused<false, BOUNCE, FULL, NBODY, true>;
+    const size_t tables = h->force_bytes, lds = persist_lds_rows(tables);
+    if ((rc = prep_kernel(kernel, lds))) return rc;
+    if ((rc = persistent_grid(h, kernel, &block, lds, h->n_packets, &grid))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
+                       (int64_t)tables, h->n_packets, h->have_order ? h->d_queue : h->d_packets,
+                       h->have_order ? h->d_order : (const unsigned *)nullptr, h->first_id, n_iter,
+                       edge2, (double *)nullptr, (long long *)nullptr, (double *)nullptr, h->d_ctr,
+                       NBODY ? h->d_moonpos : (const double *)nullptr,
+                       (const long long *)h->d_offsets, d_rec);
+    HIPCHK(hipGetLastError());
+    return end_timed(h);
+}
+
+// Pass 1 of every trajectory-producing run: the persistent integrator (optionally binning the
+// image) with final states and step counts kept on the device, then the row offsets: records
+// 0..k of a packet exist, the last one is live unless the packet died in iteration k.
+int count_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge, bool image,
+               int64_t *lengths_out, long long *total_out)
 {
     const int64_t n = h->n_packets;
-    auto kernel = k_const_traj<IMAGE, BOUNCE, NBODY>;
-    int rc = prep_kernel(kernel, lds);
-    if (rc) return rc;
-    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)lds, n, h->d_packets, h->first_id, n_iter, edge2, d_traj, nrec,
-                       d_final, d_steps, IMAGE ? h->d_image : (double *)nullptr, h->d_ctr,
-                       NBODY ? h->d_moonpos : (const double *)nullptr);
-    HIPCHK(hipGetLastError());
+    const size_t col = (size_t)n * sizeof(double);
+    int rc;
+    h->rows_total = -1;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col))) return rc;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
+                     (size_t)n * sizeof(long long))))
+        return rc;
+    if ((rc = launch_const(h, step, n_iter, outeredge, image, h->d_scratch, h->d_steps))) return rc;
+    std::vector<long long> steps((size_t)n), off((size_t)n + 1);
+    std::vector<double> frac((size_t)n);
+    HIPCHK(hipMemcpyAsync(steps.data(), h->d_steps, (size_t)n * sizeof(long long),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(frac.data(), h->d_scratch + 7 * n, col, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    long long acc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        off[(size_t)i] = acc;
+        const long long len = steps[(size_t)i] + (frac[(size_t)i] > 0.0 ? 1 : 0);
+        if (lengths_out) lengths_out[i] = len;
+        acc += len;
+    }
+    off[(size_t)n] = acc;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_offsets), &h->offsets_cap,
+                     ((size_t)n + 1) * sizeof(long long))))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->d_offsets, off.data(), ((size_t)n + 1) * sizeof(long long),
+                          hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->rows_total = acc;
+    h->rows_step = step; h->rows_edge = outeredge; h->rows_n_iter = n_iter; h->rows_n = n;
+    *total_out = acc;
     return NXC_OK;
 }
 
-// pass 2 of the compact-rows protocol; narrow: the rows leave as float32 (save()'s down-cast)
-int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
+// Pass 2: the records themselves, rec[total][10] in device memory (*d_rec_out, caller frees).
+// `reserve`: bytes the caller is about to allocate next to it (checked against free memory).
+int write_records(nxc_handle *h, size_t reserve, double **d_rec_out)
 {
     int rc = need_forces(h);
     if (rc) return rc;
-    const int64_t n = h->n_packets;
-    if (h->rows_total < 0 || h->rows_n != n)
-        return fail(NXC_ERR_STATE, "nxc_rows_fetch needs a preceding nxc_integrate_const_rows");
+    *d_rec_out = nullptr;
+    if (h->rows_total < 0 || h->rows_n != h->n_packets)
+        return fail(NXC_ERR_STATE, "the trajectory rows need a preceding nxc_integrate_const_rows");
     const long long total = h->rows_total;
-    h->rows_total = -1;
     if (total == 0) return NXC_OK;
-    if (!rows_out) return fail(NXC_ERR_ARG, "rows_out is null");
-    const size_t bytes = (size_t)9 * (size_t)total * sizeof(double);
-    const size_t out_bytes = narrow ? bytes / 2 : bytes;
+    const size_t bytes = (size_t)total * NXC_REC_DOUBLES * sizeof(double);
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (bytes + (narrow ? out_bytes : 0) > free_b)
+    if (bytes + reserve > free_b)
         return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
                                  "per call (the reference chunks too, Input.py:219-222)");
     if (h->have_bodies) {
@@ -543,68 +612,112 @@ int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
             return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
         if ((rc = upload_moon_table(h, h->rows_step, h->rows_n_iter))) return rc;
     }
-    double *d_rows = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rows), bytes + (narrow ? out_bytes : 0)));
-    float *d_narrow = reinterpret_cast<float *>(d_rows + (size_t)9 * (size_t)total);
-    if ((rc = upload_step(h, h->rows_step))) { (void)hipFree(d_rows); return rc; }
-    hipError_t e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
-    const size_t lds = h->force_bytes;
-    const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
-    const double edge2 = sqrt_threshold(h->rows_edge);
-    if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
-    if (e == hipSuccess) {
-#define NXC_LAUNCH_ROWS(BOUNCE, NBODY)                                                          \
-    do {                                                                                        \
-        auto kernel = k_const_rows<BOUNCE, NBODY>;                                              \
-        rc = prep_kernel(kernel, lds);                                                          \
-        if (!rc)                                                                                \
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(NXC_BLOCK), lds, h->stream, h->F,       \
-                               h->d_blob, (int64_t)lds, n, h->d_packets, h->first_id,           \
-                               h->rows_n_iter, edge2, h->d_offsets, total, d_rows, h->d_ctr,    \
-                               NBODY ? h->d_moonpos : (const double *)nullptr);                 \
-    } while (0)
-        if (h->have_bodies) NXC_LAUNCH_ROWS(false, true);
-        else if (h->have_bounce) NXC_LAUNCH_ROWS(true, false);
-        else NXC_LAUNCH_ROWS(false, false);
-#undef NXC_LAUNCH_ROWS
-        if (!rc) e = hipGetLastError();
+    double *d_rec = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rec), bytes));
+    rc = upload_step(h, h->rows_step);
+    if (!rc && hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream) != hipSuccess)
+        rc = fail(NXC_ERR_HIP, "hipMemsetAsync(counters) failed");
+    if (!rc) {
+        const double edge2 = sqrt_threshold(h->rows_edge);
+        const int64_t n_iter = h->rows_n_iter;
+        const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
+        if (h->have_bodies)
+            rc = full ? launch_rows<false, true, true>(h, n_iter, edge2, d_rec)
+                      : launch_rows<false, false, true>(h, n_iter, edge2, d_rec);
+        else if (h->have_bounce) rc = launch_rows<true, false, false>(h, n_iter, edge2, d_rec);
+        else rc = full ? launch_rows<false, true, false>(h, n_iter, edge2, d_rec)
+                       : launch_rows<false, false, false>(h, n_iter, edge2, d_rec);
     }
-    if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
-    if (e == hipSuccess && !rc) {
-        h->timed = true;
-        if (narrow) {
-            const int64_t cells = (int64_t)9 * total;
-            hipLaunchKernelGGL(k_narrow_f32, dim3(flat_grid(h, cells, NXC_BLOCK)), dim3(NXC_BLOCK),
-                               0, h->stream, d_rows, d_narrow, cells);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(rows_out, narrow ? static_cast<const void *>(d_narrow) : d_rows,
-                               out_bytes, hipMemcpyDeviceToHost, h->stream);
-    }
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_rows);
-    if (rc) return rc;
-    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
+    if (rc) { (void)hipFree(d_rec); return rc; }
+    *d_rec_out = d_rec;
     return NXC_OK;
 }
 
-// f-1 over stored samples, 64-bit or as save() keeps them (32-bit)
-template <typename T>
-int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, int64_t P,
-                   const T *x, const T *y, const T *z, const T *vy, const T *frac,
-                   const int64_t *index, int64_t n_index, double *radiance, int64_t *npackets,
-                   uint8_t *included, int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+template <typename T, typename I>
+int transpose_rows(nxc_handle *h, const double *d_rec, long long total, void *d_cols, void *d_index)
 {
-    if (!h || !d || S < 1 || P < 0 || !sc || !radiance || !npackets ||
-        (P && (!x || !y || !z || !vy || !frac)))
-        return fail(NXC_ERR_ARG, "bad arguments");
-    if (d->n_lines < 0 || d->n_lines > NXC_MAX_LINES || d->n_ladder < 1 || !d->ladder)
-        return fail(NXC_ERR_ARG, "bad nxc_los_desc");
-    if (included && n_index < 1) return fail(NXC_ERR_ARG, "included needs n_index");
-    if (used_pairs && (used_cap < 1 || !n_used)) return fail(NXC_ERR_ARG, "used_pairs needs a capacity");
-    HIPCHK(hipSetDevice(h->device));
+    int64_t g = (total + NXC_TR_ROWS - 1) / NXC_TR_ROWS;
+    const int64_t cap = (int64_t)h->n_cu * 16;
+    if (g > cap) g = cap;
+    hipLaunchKernelGGL((k_rows_transpose<T, I>), dim3((unsigned)g), dim3(NXC_TR_ROWS), 0, h->stream,
+                       d_rec, total, static_cast<T *>(d_cols), static_cast<I *>(d_index));
+    HIPCHK(hipGetLastError());
+    return NXC_OK;
+}
 
+// Passes 1 -> 2 -> columns: the device-resident row store of the run counted last.
+int rows_build(nxc_handle *h, bool narrow, nxc_rows **out)
+{
+    *out = nullptr;
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    const long long total = h->rows_total;
+    const size_t vsz = narrow ? sizeof(float) : sizeof(double), isz = narrow ? sizeof(int) : sizeof(long long);
+    const size_t cols_bytes = (size_t)(total > 0 ? total : 0) * 9 * vsz;
+    const size_t idx_bytes = (size_t)(total > 0 ? total : 0) * isz;
+    double *d_rec = nullptr;
+    int rc = write_records(h, cols_bytes + idx_bytes, &d_rec);
+    if (rc) return rc;
+    h->rows_total = -1;
+    nxc_rows *r = new (std::nothrow) nxc_rows();
+    if (!r) { (void)hipFree(d_rec); return fail(NXC_ERR_ARG, "out of host memory"); }
+    r->device = h->device; r->f32 = narrow; r->total = total;
+    hipError_t e = hipSuccess;
+    if (total > 0) {
+        e = hipMalloc(&r->d_cols, cols_bytes);
+        if (e == hipSuccess) e = hipMalloc(&r->d_index, idx_bytes);
+        if (e == hipSuccess)
+            rc = narrow ? transpose_rows<float, int>(h, d_rec, total, r->d_cols, r->d_index)
+                        : transpose_rows<double, long long>(h, d_rec, total, r->d_cols, r->d_index);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+    }
+    (void)hipFree(d_rec);
+    if (e != hipSuccess || rc) {
+        if (r->d_cols) (void)hipFree(r->d_cols);
+        if (r->d_index) (void)hipFree(r->d_index);
+        delete r;
+        return rc ? rc : fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
+    }
+    *out = r;
+    return NXC_OK;
+}
+
+int rows_check(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count)
+{
+    if (!h || !r) return fail(NXC_ERR_ARG, "null argument");
+    if (r->device != h->device) return fail(NXC_ERR_ARG, "the rows live on another device");
+    if (first < 0 || count < 0 || first + count > r->total)
+        return fail(NXC_ERR_ARG, "row range outside the store");
+    return NXC_OK;
+}
+
+// nxc_rows_fetch / nxc_rows_fetch_f32: build, copy out, free
+int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    if (h->rows_total < 0 || h->rows_n != h->n_packets)
+        return fail(NXC_ERR_STATE, "nxc_rows_fetch needs a preceding nxc_integrate_const_rows");
+    if (h->rows_total > 0 && !rows_out) return fail(NXC_ERR_ARG, "rows_out is null");
+    nxc_rows *r = nullptr;
+    int rc = rows_build(h, narrow, &r);
+    if (rc) return rc;
+    hipError_t e = hipSuccess;
+    if (r->total > 0) {
+        e = hipMemcpyAsync(rows_out, r->d_cols, (size_t)r->total * 9 * (narrow ? 4 : 8),
+                           hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    nxc_rows_free(h, r);
+    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows copy: ") + hipGetErrorString(e));
+    return NXC_OK;
+}
+
+// f-1 over stored samples that are already on the device (64-bit, or 32-bit as save() keeps them)
+template <typename T, typename I>
+int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, int64_t P,
+            const T *dx, const T *dy, const T *dz, const T *dvy, const T *dfrac, const I *d_index,
+            int64_t index_shift, int64_t n_index, double *radiance, int64_t *npackets, uint8_t *included,
+            int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+{
     // LDS block: [header space | g-value tables | spectra tile]
     std::vector<unsigned char> blob((size_t)NXC_HEADER_BYTES, 0);
     std::memcpy(blob.data(), &h->header, sizeof(LdsHeader));      // nxc_log's table lives there
@@ -619,6 +732,7 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
     K.log1p_s_inv = 1.0 / std::log1p(d->sin_dphi);
     K.n_lines = d->n_lines;
     K.n_ladder = (int)d->n_ladder;
+    K.index_shift = index_shift;
     for (int l = 0; l < d->n_lines; l++) {
         PackedLut lut;
         int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
@@ -631,12 +745,11 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
     const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double);
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
-    // device buffers: blob | sc | samples(5) | index | ladder | radiance | npackets | included | used
-    const size_t colP = (size_t)P * sizeof(T);
+    // device scratch: blob | sc | ladder | radiance | npackets | included | used
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~size_t(255); return o; };
-    const size_t o_blob = take(stage_bytes), o_sc = take((size_t)8 * S * 8), o_smp = take(5 * colP),
-                 o_idx = take(index ? (size_t)P * 8 : 0), o_lad = take((size_t)d->n_ladder * 8),
+    const size_t o_blob = take(stage_bytes), o_sc = take((size_t)8 * S * 8),
+                 o_lad = take((size_t)d->n_ladder * 8),
                  o_rad = take((size_t)S * 8), o_np = take((size_t)S * 8),
                  o_inc = take(included ? (size_t)n_index : 0),
                  o_used = take(used_pairs ? (size_t)used_cap * 16 : 0), o_nu = take(8);
@@ -646,10 +759,6 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
     hipStream_t st = h->stream;
     HIPCHK(hipMemcpyAsync(base + o_blob, blob.data(), stage_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(base + o_sc, sc, (size_t)8 * S * 8, hipMemcpyHostToDevice, st));
-    const T *cols[5] = {x, y, z, vy, frac};
-    for (int c = 0; c < 5 && P; c++)
-        HIPCHK(hipMemcpyAsync(base + o_smp + c * colP, cols[c], colP, hipMemcpyHostToDevice, st));
-    if (index && P) HIPCHK(hipMemcpyAsync(base + o_idx, index, (size_t)P * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(base + o_lad, d->ladder, (size_t)d->n_ladder * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(base + o_rad, 0, (size_t)S * 8, st));
     HIPCHK(hipMemsetAsync(base + o_np, 0, (size_t)S * 8, st));
@@ -657,16 +766,14 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
     HIPCHK(hipMemsetAsync(base + o_nu, 0, 8, st));
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), st));
     if (P > 0) {
-        if ((rc = prep_kernel(k_los<T>, lds))) return rc;
+        if ((rc = prep_kernel(k_los<T, I>, lds))) return rc;
         const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
         int gx = flat_grid(h, P, NXC_BLOCK);
         if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
-        const T *smp = reinterpret_cast<const T *>(base + o_smp);
         if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL(k_los<T>, dim3(gx, tiles), dim3(NXC_BLOCK), lds, st, K, base + o_blob,
+        hipLaunchKernelGGL((k_los<T, I>), dim3(gx, tiles), dim3(NXC_BLOCK), lds, st, K, base + o_blob,
                            (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc), P,
-                           smp, smp + P, smp + 2 * P, smp + 3 * P, smp + 4 * P,
-                           index ? reinterpret_cast<const long long *>(base + o_idx) : nullptr,
+                           dx, dy, dz, dvy, dfrac, d_index,
                            reinterpret_cast<const double *>(base + o_lad),
                            reinterpret_cast<double *>(base + o_rad),
                            reinterpret_cast<unsigned long long *>(base + o_np),
@@ -692,7 +799,66 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
     return NXC_OK;
 }
 
-// a-6..a-8 over stored samples, 64-bit or as save() keeps them (32-bit)
+int los_check(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, int64_t P,
+              const double *radiance, const int64_t *npackets, const uint8_t *included,
+              int64_t n_index, int64_t used_cap, const int64_t *used_pairs, const int64_t *n_used)
+{
+    if (!h || !d || S < 1 || P < 0 || !sc || !radiance || !npackets)
+        return fail(NXC_ERR_ARG, "bad arguments");
+    if (d->n_lines < 0 || d->n_lines > NXC_MAX_LINES || d->n_ladder < 1 || !d->ladder)
+        return fail(NXC_ERR_ARG, "bad nxc_los_desc");
+    if (included && n_index < 1) return fail(NXC_ERR_ARG, "included needs n_index");
+    if (used_pairs && (used_cap < 1 || !n_used)) return fail(NXC_ERR_ARG, "used_pairs needs a capacity");
+    HIPCHK(hipSetDevice(h->device));
+    return NXC_OK;
+}
+
+// ... over samples in host memory: five columns (+ the index column) go to the device first
+template <typename T>
+int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, int64_t P,
+                   const T *x, const T *y, const T *z, const T *vy, const T *frac,
+                   const int64_t *index, int64_t n_index, double *radiance, int64_t *npackets,
+                   uint8_t *included, int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+{
+    int rc = los_check(h, d, S, sc, P, radiance, npackets, included, n_index, used_cap, used_pairs,
+                       n_used);
+    if (rc) return rc;
+    if (P && (!x || !y || !z || !vy || !frac)) return fail(NXC_ERR_ARG, "bad arguments");
+    const size_t colP = ((size_t)P * sizeof(T) + 255) & ~size_t(255);
+    const size_t idx_bytes = index ? (size_t)P * 8 : 0;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_samples), &h->samples_cap, 5 * colP + idx_bytes)))
+        return rc;
+    const T *cols[5] = {x, y, z, vy, frac};
+    for (int c = 0; c < 5 && P; c++)
+        HIPCHK(hipMemcpyAsync(h->d_samples + c * colP, cols[c], (size_t)P * sizeof(T),
+                              hipMemcpyHostToDevice, h->stream));
+    if (index && P)
+        HIPCHK(hipMemcpyAsync(h->d_samples + 5 * colP, index, idx_bytes, hipMemcpyHostToDevice, h->stream));
+    auto col = [&](int c) { return reinterpret_cast<const T *>(h->d_samples + c * colP); };
+    return los_run<T, long long>(h, d, S, sc, P, col(0), col(1), col(2), col(3), col(4),
+                                 index ? reinterpret_cast<const long long *>(h->d_samples + 5 * colP)
+                                       : (const long long *)nullptr,
+                                 0, n_index, radiance, npackets, included, used_cap, used_pairs, n_used);
+}
+
+// a-6..a-8 over samples on the device
+template <typename T>
+int image_run(nxc_handle *h, int64_t p, const T *dx, const T *dy, const T *dz, const T *dvy,
+              const T *dfrac)
+{
+    int rc;
+    if ((rc = prep_kernel(k_image<T>, h->all_bytes))) return rc;
+    if ((rc = begin_timed(h))) return rc;
+    hipLaunchKernelGGL(k_image<T>, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
+                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, dx, dy, dz, dvy, dfrac,
+                       h->d_image, h->d_ctr);
+    HIPCHK(hipGetLastError());
+    if ((rc = end_timed(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
+// ... over samples in host memory, 64-bit or as save() keeps them (32-bit)
 template <typename T>
 int image_accumulate(nxc_handle *h, int64_t p, const T *x, const T *y, const T *z, const T *vy,
                      const T *frac)
@@ -703,21 +869,13 @@ int image_accumulate(nxc_handle *h, int64_t p, const T *x, const T *y, const T *
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     if (p == 0) return NXC_OK;
     const size_t col = (size_t)p * sizeof(T);
-    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 5 * col);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_samples), &h->samples_cap, 5 * col);
     if (rc) return rc;
-    T *d = reinterpret_cast<T *>(h->d_scratch);
+    T *d = reinterpret_cast<T *>(h->d_samples);
     const T *src[5] = {x, y, z, vy, frac};
     for (int c = 0; c < 5; c++)
         HIPCHK(hipMemcpyAsync(d + c * p, src[c], col, hipMemcpyHostToDevice, h->stream));
-    if ((rc = prep_kernel(k_image<T>, h->all_bytes))) return rc;
-    if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(k_image<T>, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
-                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, d, d + p, d + 2 * p,
-                       d + 3 * p, d + 4 * p, h->d_image, h->d_ctr);
-    HIPCHK(hipGetLastError());
-    if ((rc = end_timed(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return NXC_OK;
+    return image_run<T>(h, p, d, d + p, d + 2 * p, d + 3 * p, d + 4 * p);
 }
 
 }  // namespace
@@ -786,7 +944,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
-                    h->d_source, h->d_queue};
+                    h->d_source, h->d_queue, h->d_samples};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1330,59 +1488,63 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
     const size_t col = (size_t)n * sizeof(double);
     double *d_final = nullptr;
     long long *d_steps = nullptr;
-    if (final_out) {
-        if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col)))
-            return rc;
-        d_final = h->d_scratch;
-    }
-    if (steps_out) {
-        if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
-                         (size_t)n * sizeof(long long))))
-            return rc;
-        d_steps = h->d_steps;
-    }
     if (!traj_out) {
+        if (final_out) {
+            if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col)))
+                return rc;
+            d_final = h->d_scratch;
+        }
+        if (steps_out) {
+            if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
+                             (size_t)n * sizeof(long long))))
+                return rc;
+            d_steps = h->d_steps;
+        }
         if ((rc = launch_const(h, step, n_iter, outeredge, image, d_final, d_steps))) return rc;
     } else {
+        // the dense `results` array of the reference (Output.py:376,419): pass 1 (persistent
+        // integrator, + image) -> row offsets -> pass 2 writes the live records -> k_rows_densify
+        // lays them out [column][record][packet] with the death record and the zero padding
         const size_t tbytes = (size_t)8 * (size_t)nrec * col;
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
         if (tbytes > free_b)
             return fail(NXC_ERR_ARG, "trajectory buffer does not fit in device memory; run fewer "
                                      "packets per call (the reference chunks too, Input.py:219-222)");
-        if (h->have_bodies) {
-            if (h->have_bounce)
-                return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
-            if ((rc = upload_moon_table(h, step, n_iter))) return rc;
-        }
+        long long total = 0;
+        if ((rc = count_rows(h, step, n_iter, outeredge, image, nullptr, &total))) return rc;
+        // the caller's counters are those of pass 1 (work, samples); pass 2 re-does the steps
+        DevCounters pass1;
+        HIPCHK(hipMemcpyAsync(&pass1, h->d_ctr, sizeof pass1, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        d_final = h->d_scratch;
+        d_steps = h->d_steps;
+        double *d_rec = nullptr;
+        if ((rc = write_records(h, tbytes, &d_rec))) return rc;
+        h->rows_total = -1;
         double *d_traj = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes));
-        if ((rc = upload_step(h, step))) { (void)hipFree(d_traj); return rc; }
-        hipError_t e = hipMemsetAsync(d_traj, 0, tbytes, h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream);
-        const size_t lds = image ? h->all_bytes : h->force_bytes;
-        const int grid = (int)((n + NXC_BLOCK - 1) / NXC_BLOCK);
-        if (e == hipSuccess) e = hipEventRecord(h->ev0, h->stream);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes);
         if (e == hipSuccess) {
-            const double edge2 = sqrt_threshold(outeredge);
-            if (h->have_bodies)
-                rc = image ? launch_traj<true, false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
-                           : launch_traj<false, false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
-            else if (image)
-                rc = h->have_bounce ? launch_traj<true, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
-                                    : launch_traj<true, false>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
-            else
-                rc = h->have_bounce ? launch_traj<false, true>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps)
-                                    : launch_traj<false, false>(h, lds, n_iter, edge2, d_traj, nrec, d_final, d_steps);
+            const dim3 grid((unsigned)((n + NXC_BLOCK - 1) / NXC_BLOCK),
+                            (unsigned)((nrec + NXC_DENSIFY_RECORDS - 1) / NXC_DENSIFY_RECORDS));
+            hipLaunchKernelGGL(k_rows_densify, grid, dim3(NXC_BLOCK), 0, h->stream, d_rec,
+                               (const long long *)h->d_offsets, (const double *)d_final,
+                               (const long long *)d_steps, n, nrec, d_traj);
+            e = hipGetLastError();
         }
-        if (e == hipSuccess && !rc) e = hipEventRecord(h->ev1, h->stream);
-        if (e == hipSuccess && !rc) {
-            h->timed = true;
+        DevCounters pass2;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&pass2, h->d_ctr, sizeof pass2, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess)
             e = hipMemcpyAsync(traj_out, d_traj, tbytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) {
+            pass1.unfinished += pass2.unfinished;        // rows the two passes disagree on
+            e = hipMemcpyAsync(h->d_ctr, &pass1, sizeof pass1, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         }
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
-        (void)hipFree(d_traj);
-        if (rc) return rc;
+        if (d_traj) (void)hipFree(d_traj);
+        if (d_rec) (void)hipFree(d_rec);
         if (e != hipSuccess)
             return fail(NXC_ERR_HIP, std::string("trajectory run: ") + hipGetErrorString(e));
     }
@@ -1402,41 +1564,111 @@ int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double 
     return guarded([&]() -> int {
     int rc = need_forces(h);
     if (rc) return rc;
-    const int64_t n = h->n_packets;
-    if (n < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
+    if (h->n_packets < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
     if (!(step > 0) || n_iter < 0 || !total_out) return fail(NXC_ERR_ARG, "bad arguments");
-    h->rows_total = -1;
-    const size_t col = (size_t)n * sizeof(double);
-    if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 8 * col))) return rc;
-    if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap,
-                     (size_t)n * sizeof(long long))))
-        return rc;
-    if ((rc = launch_const(h, step, n_iter, outeredge, false, h->d_scratch, h->d_steps))) return rc;
-    std::vector<long long> steps((size_t)n), off((size_t)n + 1);
-    std::vector<double> frac((size_t)n);
-    HIPCHK(hipMemcpyAsync(steps.data(), h->d_steps, (size_t)n * sizeof(long long),
-                          hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(frac.data(), h->d_scratch + 7 * n, col, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    // records 0..k exist; the last one is live unless the packet died in iteration k
-    long long acc = 0;
-    for (int64_t i = 0; i < n; i++) {
-        off[(size_t)i] = acc;
-        const long long len = steps[(size_t)i] + (frac[(size_t)i] > 0.0 ? 1 : 0);
-        if (lengths_out) lengths_out[i] = len;
-        acc += len;
-    }
-    off[(size_t)n] = acc;
-    if ((rc = ensure(reinterpret_cast<void **>(&h->d_offsets), &h->offsets_cap,
-                     ((size_t)n + 1) * sizeof(long long))))
-        return rc;
-    HIPCHK(hipMemcpyAsync(h->d_offsets, off.data(), ((size_t)n + 1) * sizeof(long long),
-                          hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->rows_total = acc;
-    h->rows_step = step; h->rows_edge = outeredge; h->rows_n_iter = n_iter; h->rows_n = n;
-    *total_out = acc;
+    long long total = 0;
+    if ((rc = count_rows(h, step, n_iter, outeredge, false, lengths_out, &total))) return rc;
+    *total_out = total;
     return NXC_OK;
+    });
+}
+
+int nxc_rows_build(nxc_handle *h, int narrow, nxc_rows **out)
+{
+    return guarded([&]() -> int {
+    if (!out) return fail(NXC_ERR_ARG, "out is null");
+    if (!h || h->rows_total < 0 || h->rows_n != h->n_packets)
+        return fail(NXC_ERR_STATE, "nxc_rows_build needs a preceding nxc_integrate_const_rows");
+    return rows_build(h, narrow != 0, out);
+    });
+}
+
+int nxc_rows_info(const nxc_rows *r, int64_t *total, int32_t *is_f32)
+{
+    if (!r) return fail(NXC_ERR_ARG, "null argument");
+    if (total) *total = r->total;
+    if (is_f32) *is_f32 = r->f32 ? 1 : 0;
+    return NXC_OK;
+}
+
+int nxc_rows_free(nxc_handle *h, nxc_rows *r)
+{
+    if (!r) return NXC_OK;
+    (void)hipSetDevice(r->device);
+    if (h && h->stream) (void)hipStreamSynchronize(h->stream);
+    if (r->d_cols) (void)hipFree(r->d_cols);
+    if (r->d_index) (void)hipFree(r->d_index);
+    delete r;
+    return NXC_OK;
+}
+
+int nxc_rows_download(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count,
+                      void *cols_out, void *index_out)
+{
+    return guarded([&]() -> int {
+    int rc = rows_check(h, r, first, count);
+    if (rc) return rc;
+    if (count == 0) return NXC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t vsz = r->f32 ? 4 : 8, isz = r->f32 ? 4 : 8;
+    if (cols_out)          // nine strided column pieces -> [9][count]
+        HIPCHK(hipMemcpy2DAsync(cols_out, (size_t)count * vsz,
+                                static_cast<const char *>(r->d_cols) + (size_t)first * vsz,
+                                (size_t)r->total * vsz, (size_t)count * vsz, 9,
+                                hipMemcpyDeviceToHost, h->stream));
+    if (index_out)
+        HIPCHK(hipMemcpyAsync(index_out, static_cast<const char *>(r->d_index) + (size_t)first * isz,
+                              (size_t)count * isz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+    });
+}
+
+int nxc_image_accumulate_rows(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count)
+{
+    return guarded([&]() -> int {
+    if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
+    int rc = rows_check(h, r, first, count);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    if (count == 0) return NXC_OK;
+    // columns 1, 2, 3, 5, 7 of the store = x, y, z, vy, frac
+    if (r->f32) {
+        const float *c = static_cast<const float *>(r->d_cols) + first;
+        const long long t = r->total;
+        return image_run<float>(h, count, c + t, c + 2 * t, c + 3 * t, c + 5 * t, c + 7 * t);
+    }
+    const double *c = static_cast<const double *>(r->d_cols) + first;
+    const long long t = r->total;
+    return image_run<double>(h, count, c + t, c + 2 * t, c + 3 * t, c + 5 * t, c + 7 * t);
+    });
+}
+
+int nxc_los_accumulate_rows(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc,
+                            const nxc_rows *r, int64_t first, int64_t count, int64_t index_shift,
+                            int64_t n_index,
+                            double *radiance, int64_t *npackets, uint8_t *included,
+                            int64_t used_cap, int64_t *used_pairs, int64_t *n_used)
+{
+    return guarded([&]() -> int {
+    int rc = los_check(h, d, S, sc, count, radiance, npackets, included, n_index, used_cap,
+                       used_pairs, n_used);
+    if (rc) return rc;
+    if ((rc = rows_check(h, r, first, count))) return rc;
+    const long long t = r->total;
+    if (r->f32) {
+        const float *c = static_cast<const float *>(r->d_cols) + first;
+        return los_run<float, int>(h, d, S, sc, count, c + t, c + 2 * t, c + 3 * t, c + 5 * t,
+                                   c + 7 * t, static_cast<const int *>(r->d_index) + first, index_shift,
+                                   n_index,
+                                   radiance, npackets, included, used_cap, used_pairs, n_used);
+    }
+    const double *c = static_cast<const double *>(r->d_cols) + first;
+    return los_run<double, long long>(h, d, S, sc, count, c + t, c + 2 * t, c + 3 * t, c + 5 * t,
+                                      c + 7 * t, static_cast<const long long *>(r->d_index) + first,
+                                      index_shift, n_index, radiance, npackets, included, used_cap, used_pairs,
+                                      n_used);
     });
 }
 
@@ -1466,14 +1698,14 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
         return rc;
     double *d_final = h->d_scratch, *d_hs = d_final + 8 * n;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
-    int grid = 1;
+    int grid = 1, block = BLOCK_PERSIST;
     const size_t lds = persist_lds(h->force_bytes);
     const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
     auto kernel = full ? k_var<true> : k_var<false>;
     if ((rc = prep_kernel(kernel, lds))) return rc;
-    if ((rc = persistent_grid(h, kernel, BLOCK_PERSIST, lds, n, &grid))) return rc;
+    if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
     if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK_PERSIST), lds, h->stream, h->F, h->d_blob,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
                        (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
                        h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge, (long long)max_steps,
                        d_final, d_hs, h->d_ctr);

@@ -418,6 +418,7 @@ struct LoopK {
     long long *steps_out;
     unsigned long long *head;
     long long n;
+    const long long *offsets;     // ROWS pass: row offsets per packet index
 };
 // Refined reciprocals of the two launch-constant divisors of the weight (1e6, Apix), computed once
 // per workgroup; read from LDS by the samples that fall inside the image.

@@ -2,14 +2,14 @@
 //
 //   k_state         a-2  element-wise force/loss model
 //   k_rk5_step      a-1  one Dormand-Prince step per packet, per-packet step size
-//   k_const_traj    a-3  lock-step constant-step driver that streams every record to HBM
-//                        ([column][record][packet]: each store is coalesced across the wave)
 //   k_const_fused   a-3 + a-6..a-8  persistent LANE-REFILL integrator: a lane keeps its packet's
 //                        state in registers until the packet dies, then takes the next packet
 //                        from a global queue (claimed in chunks, handed out inside the wave by
 //                        ballot + prefix rank), so waves stay full although lifetimes differ by
 //                        three orders of magnitude.  Every stored record is binned straight into
 //                        the image; the (N, 8, nsteps) trajectory tensor is never materialised.
+//                        <ROWS>: the same loop writes every live record to its row of the
+//                        compact trajectory instead (k_rows_transpose / k_rows_densify shape it).
 //   k_var           a-4  adaptive-step driver, same lane-refill structure
 //   k_image         a-6..a-8  image of stored samples (HBM-bound: 40 B/sample in)
 //
@@ -59,6 +59,8 @@ static_assert(NXC_CHUNK >= 1 && NXC_CHUNK <= 64, "a chunk is loaded by one wave"
 constexpr int NXC_WAVE_STAGE_BYTES = NXC_CHUNK * 9 * 8;   // per-wave LDS staging: 8 columns + packet id
 // per-wave LDS of the persistent kernels: the packet staging block, then the image queue
 constexpr int NXC_WAVE_LDS_BYTES = NXC_WAVE_STAGE_BYTES + NXC_IMGQ_BYTES;
+// the ROWS variant stages two more columns (first row, row count) and has no image queue
+constexpr int NXC_WAVE_LDS_BYTES_ROWS = NXC_CHUNK * 11 * 8;
 
 // Cooperative copy of the first `bytes` (multiple of 8) of the table blob into LDS, then the
 // derived per-launch constants of the header.
@@ -85,13 +87,14 @@ NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
 // stage_tables + the loop's rarely used kernel arguments parked in the LDS header (LoopK).
 NXC_DEV void stage_tables_and_args(const unsigned char *__restrict__ blob, int64_t bytes,
                                    const double *soa0, const unsigned *order, double *final_out,
-                                   long long *steps_out, unsigned long long *head, long long n)
+                                   long long *steps_out, unsigned long long *head, long long n,
+                                   const long long *offsets = nullptr)
 {
     stage_tables(blob, bytes);
     if (threadIdx.x == 0) {
         LoopK &L = lds_header_rw().L;
         L.soa0 = soa0; L.order = order; L.final_out = final_out; L.steps_out = steps_out;
-        L.head = head; L.n = n;
+        L.head = head; L.n = n; L.offsets = offsets;
     }
     __syncthreads();
 }
@@ -157,141 +160,84 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lock-step driver with trajectory output.  traj is pre-zeroed: dead packets leave zero records,
-// like the reference's `results` (Output.py:376).
-template <bool IMAGE, bool BOUNCE, bool NBODY = false>
-__global__ void __launch_bounds__(NXC_BLOCK)
-k_const_traj(ForceK F, const unsigned char *__restrict__ blob,
-             int64_t stage_bytes, int64_t n, const double *__restrict__ soa0, int64_t first_id,
-             int64_t n_iter, double edge2, double *__restrict__ traj, int64_t nrec,
-             double *__restrict__ final_out, long long *__restrict__ steps_out,
-             double *__restrict__ acc2, DevCounters *__restrict__ ctr,
-             const double *__restrict__ moon_pos = nullptr)
+// Trajectory records.  The trajectory-producing runs (the reference's default user flow:
+// Output.py:435-449 builds X from every record, save() keeps those with frac > 0, :523-524) use
+// the same persistent lane-refill integrator as the fused image pass (k_const_fused<ROWS>): a
+// first pass counts every packet's live records, the host turns the counts into row offsets, and
+// the second pass writes record k of packet i at row offsets[i] + k.  A lane owns its packet for
+// the packet's whole life, so its records are consecutive rows; they are written as 80-byte
+// array-of-structures records {t, x, y, z, vx, vy, vz, frac, lossfrac, packet index} (five
+// aligned 16-byte stores per record; a 128-byte line is completed by two consecutive steps of
+// one lane), and k_rows_transpose turns the finished block into the columns the host wants
+// (struct-of-arrays, optionally narrowed to float32 / int32: save()'s down-cast, Output.py:528-543).
+constexpr int NXC_REC_DOUBLES = 10;
+
+NXC_DEV void store_record(double *__restrict__ rec, long long row, const double (&s)[8],
+                          double lossfrac, long long id)
 {
-    stage_tables(blob, stage_bytes);
-    const LutView T = lut_view(F.tab);
-    ImageRegs IR{};
-    if (IMAGE) IR = image_regs(lds_header().G);
-    unsigned long long my_steps = 0, my_samples = 0, my_binned = 0, my_nonfinite = 0;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = i < n;
-    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d[8];
-    if (valid) {
+    nxc_v2d *p = reinterpret_cast<nxc_v2d *>(rec + row * NXC_REC_DOUBLES);   // 16-byte aligned
+    nxc_v2d a, b, c, d, e;
+    a.x = s[0]; a.y = s[1]; b.x = s[2]; b.y = s[3]; c.x = s[4]; c.y = s[5]; d.x = s[6]; d.y = s[7];
+    e.x = lossfrac; e.y = __longlong_as_double(id);
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e;
+}
+
+// rec[total][10] -> cols[9][total] and index[total]; T = double | float,
+// I = long long | int.  A block moves 256 records through LDS: coalesced 16-byte reads, coalesced
+// column writes.
+constexpr int NXC_TR_ROWS = 256;
+template <typename T, typename I>
+__global__ void __launch_bounds__(NXC_TR_ROWS)
+k_rows_transpose(const double *__restrict__ rec, long long total, T *__restrict__ cols,
+                 I *__restrict__ index)
+{
+    __shared__ nxc_v2d tile[NXC_TR_ROWS * NXC_REC_DOUBLES / 2];
+    for (long long base = (long long)blockIdx.x * NXC_TR_ROWS; base < total;
+         base += (long long)gridDim.x * NXC_TR_ROWS) {
+        const int nrow = (int)((total - base) < NXC_TR_ROWS ? (total - base) : NXC_TR_ROWS);
+        const nxc_v2d *src = reinterpret_cast<const nxc_v2d *>(rec + base * NXC_REC_DOUBLES);
+        for (int w = threadIdx.x; w < nrow * (NXC_REC_DOUBLES / 2); w += NXC_TR_ROWS) tile[w] = src[w];
+        __syncthreads();
+        if ((int)threadIdx.x < nrow) {
+            const double *r = reinterpret_cast<const double *>(tile) + threadIdx.x * NXC_REC_DOUBLES;
+            const long long row = base + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < 8; c++) s[c] = soa0[c * n + i];
-#pragma unroll
-        for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec) * n + i] = s[c];
-    }
-    bool alive = valid && s[7] > 0.0;
-    long long k = 0;
-    int nbounce = 0;
-    // The loop is wave-uniform (it runs while any lane still has steps to take) because the image
-    // accumulation is wave-cooperative; each lane works under its own predicate.
-    if (IMAGE) {
-        my_samples += alive;
-        image_sample(lds_header().G, IR, alive, s[1], s[2], s[3], s[5], s[7], acc2, my_binned,
-                     my_nonfinite);
-    }
-    while (__ballot(alive && k < n_iter) != 0) {
-        bool sample = false;
-        if (alive && k < n_iter) {
-            if (NBODY) {
-                const BodyK *Bd = &lds_header().Bd;
-                const double *mp = moon_pos + k * (2 * Bd->n_moons);
-                rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
-                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp);
-            } else {
-                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
-            }
-            k++; my_steps++;
-            if (k < nrec) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec + k) * n + i] = s[c];
-            }
-            alive = s[7] > 0.0;
-            sample = alive;
+            for (int c = 0; c < 9; c++) cols[c * total + row] = (T)r[c];
+            index[row] = (I)__double_as_longlong(r[9]);
         }
-        if (IMAGE) {
-            my_samples += sample;
-            image_sample(lds_header().G, IR, sample, s[1], s[2], s[3], s[5], s[7], acc2,
-                         my_binned, my_nonfinite);
-        }
-    }
-    if (valid) {
-        if (final_out) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) final_out[c * n + i] = s[c];
-        }
-        if (steps_out) steps_out[i] = k;
-    }
-    flush_counter(&ctr->particle_steps, my_steps);
-    if (IMAGE) {
-        flush_counter(&ctr->samples, my_samples);
-        flush_counter(&ctr->samples_binned, my_binned);
-        flush_counter(&ctr->nonfinite, my_nonfinite);
+        __syncthreads();
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Lock-step driver writing only the live records (frac > 0), packet-major: row offsets[i] + k of
-// rows[9][total] is packet i after k iterations; column 8 is lossfrac (Output.py:420-421).
-template <bool BOUNCE, bool NBODY>
+// The reference's dense `results` array (Output.py:376,419), transposed: traj[c][k][i] for
+// c < 8, k < nrec.  Record k of packet i is its live record k (k < len), the state in which it
+// died (k == steps[i] when that record is not live: frac = 0 and t = 0 but the position stays,
+// Output.py:413-419), and zero afterwards.  Thread i walks its own consecutive records; every
+// store is coalesced across the packets.  blockIdx.y cuts the record axis.
+constexpr int NXC_DENSIFY_RECORDS = 32;
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_const_rows(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
-             const double *__restrict__ soa0, int64_t first_id, int64_t n_iter, double edge2,
-             const long long *__restrict__ offsets, long long total, double *__restrict__ rows,
-             DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos)
+k_rows_densify(const double *__restrict__ rec, const long long *__restrict__ offsets,
+               const double *__restrict__ final_soa, const long long *__restrict__ steps,
+               int64_t n, int64_t nrec, double *__restrict__ traj)
 {
-    stage_tables(blob, stage_bytes);
-    const LutView T = lut_view(F.tab);
-    unsigned long long my_steps = 0, my_overrun = 0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        double s[8], d[8];
+    if (i >= n) return;
+    const long long off = offsets[i], len = offsets[i + 1] - off, last = steps[i];
+    const int64_t k0 = (int64_t)blockIdx.y * NXC_DENSIFY_RECORDS;
+    const int64_t k1 = k0 + NXC_DENSIFY_RECORDS < nrec ? k0 + NXC_DENSIFY_RECORDS : nrec;
+    for (int64_t k = k0; k < k1; k++) {
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < len) {
+            const nxc_v2d *r = reinterpret_cast<const nxc_v2d *>(rec + (off + k) * NXC_REC_DOUBLES);
 #pragma unroll
-        for (int c = 0; c < 8; c++) s[c] = soa0[c * n + i];
-        const long long off = offsets[i], len = offsets[i + 1] - off;
-        double lossfrac = 0.0;
-        long long k = 0;
-        int nbounce = 0;
-        bool alive = s[7] > 0.0;
-        if (alive) {
-            if (len > 0) {
+            for (int c = 0; c < 4; c++) { const nxc_v2d t = r[c]; v[2 * c] = t.x; v[2 * c + 1] = t.y; }
+        } else if (k == last) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) rows[(long long)c * total + off] = s[c];
-                rows[8ll * total + off] = 0.0;
-            } else {
-                my_overrun++;
-            }
+            for (int c = 0; c < 8; c++) v[c] = final_soa[c * n + i];
         }
-        while (alive && k < n_iter) {
-            const double before = s[7];
-            if (NBODY) {
-                const BodyK *Bd = &lds_header().Bd;
-                const double *mp = moon_pos + k * (2 * Bd->n_moons);
-                rk5_step<false, true, false, true>(F, T, s, 0.0, lds_header().W, d, Bd, mp);
-                apply_fate<false, true>(s, edge2, 0ull, nbounce, Bd, mp);
-            } else {
-                rk5_step<false, true>(F, T, s, 0.0, lds_header().W, d);
-                apply_fate<BOUNCE>(s, edge2, (unsigned long long)(first_id + i), nbounce);
-            }
-            k++; my_steps++;
-            lossfrac = (lossfrac + before) - s[7];
-            alive = s[7] > 0.0;
-            if (alive) {
-                if (k < len) {
 #pragma unroll
-                    for (int c = 0; c < 8; c++) rows[(long long)c * total + off + k] = s[c];
-                    rows[8ll * total + off + k] = lossfrac;
-                } else {
-                    my_overrun++;       // the two passes disagree: reported, never written
-                }
-            }
-        }
+        for (int c = 0; c < 8; c++) traj[((int64_t)c * nrec + k) * n + i] = v[c];
     }
-    flush_counter(&ctr->particle_steps, my_steps);
-    flush_counter(&ctr->unfinished, my_overrun);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -322,7 +268,11 @@ struct WaveQueue {
             pending = (long long)atomicAdd(lds_header().L.head, (unsigned long long)NXC_CHUNK);
     }
 
-    NXC_DEV long long refill(bool need, int stage_off, double (&s)[8])
+    // ROWS: the packet's first row and row count (offsets[id], offsets[id + 1] - offsets[id]) are
+    // staged with it and returned in row0 / nrow.
+    template <bool ROWS = false>
+    NXC_DEV long long refill(bool need, int stage_off, double (&s)[8], long long *row0 = nullptr,
+                             long long *nrow = nullptr)
     {
         const unsigned long long mask = __ballot(need);
         long long mine = -1;
@@ -347,7 +297,14 @@ struct WaveQueue {
                     const long long src = b + lane;
 #pragma unroll
                     for (int c = 0; c < 8; c++) stage[c * NXC_CHUNK + lane] = soa0[c * n + src];
-                    stage[8 * NXC_CHUNK + lane] = __longlong_as_double(ids ? (long long)ids[src] : src);
+                    const long long pid = ids ? (long long)ids[src] : src;
+                    stage[8 * NXC_CHUNK + lane] = __longlong_as_double(pid);
+                    if (ROWS) {
+                        const long long *__restrict__ offs = L.offsets;
+                        const long long o0 = offs[pid], o1 = offs[pid + 1];
+                        stage[9 * NXC_CHUNK + lane] = __longlong_as_double(o0);
+                        stage[10 * NXC_CHUNK + lane] = __longlong_as_double(o1 - o0);
+                    }
                 }
                 if (lane == 0) pending = (long long)atomicAdd(L.head, (unsigned long long)NXC_CHUNK);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -360,6 +317,10 @@ struct WaveQueue {
                 mine = __double_as_longlong(stage[8 * NXC_CHUNK + slot]);
 #pragma unroll
                 for (int c = 0; c < 8; c++) s[c] = stage[c * NXC_CHUNK + slot];
+                if (ROWS) {
+                    *row0 = __double_as_longlong(stage[9 * NXC_CHUNK + slot]);
+                    *nrow = __double_as_longlong(stage[10 * NXC_CHUNK + slot]);
+                }
             }
             c_pos += take;
             served += take;
@@ -371,16 +332,22 @@ struct WaveQueue {
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
-template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false>
+// ROWS (never with IMAGE): every live record -- the initial state and the state after each step
+// while frac > 0 -- goes to row offsets[id] + k of rec[total][10] with lossfrac accumulated as
+// (lossfrac + frac_before) - frac_after per step (Output.py:420-421) from 0.
+template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, bool ROWS = false>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
               const unsigned *__restrict__ order, int64_t first_id, int64_t n_iter,
               double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ acc2,
-              DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr)
+              DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr,
+              const long long *__restrict__ offsets = nullptr, double *__restrict__ rec = nullptr)
 {
-    stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n);
+    static_assert(!(IMAGE && ROWS), "the rows pass has no image");
+    stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n,
+                          offsets);
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
@@ -394,10 +361,13 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     // the bench's loop from looking the pointers up every time a packet ends
     const bool want_out = __builtin_amdgcn_readfirstlane(
         (final_out != nullptr || steps_out != nullptr) ? 1 : 0) != 0;
-    const int wave_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
+    const int wave_off = (int)((stage_bytes + 31) & ~31ll) +
+                         (threadIdx.x >> 6) * (ROWS ? NXC_WAVE_LDS_BYTES_ROWS : NXC_WAVE_LDS_BYTES);
     const int stage_off = wave_off, imgq_off = wave_off + NXC_WAVE_STAGE_BYTES;
     bool has = false, fresh = false;
-    long long id = -1;
+    long long id = -1, row0 = 0, nrow = 0;
+    double lossfrac = 0.0;
+    unsigned my_overrun = 0;
     int k = 0, nbounce = 0;
     const int n_it = n_iter > 0x7fffffffll ? 0x7fffffff : (int)n_iter;
     double s[8], d[8];
@@ -411,13 +381,14 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = nxc_stamp();
 #endif
     for (;;) {
-        const long long got = q.refill(!has, stage_off, s);
-        if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; }
+        const long long got = q.refill<ROWS>(!has, stage_off, s, &row0, &nrow);
+        if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; lossfrac = 0.0; }
         if (__ballot(has) == 0) break;
         NXC_STAMP(0);                                  // refill
         int p = -1;
         double rv = 0.0, fw = 0.0;
         if (has) {
+            const double before = s[7];
             if (!fresh) {
                 if (NBODY) {
                     const BodyK *Bd = &lds_header().Bd;
@@ -448,10 +419,15 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
                 }
 #endif
                 k++; my_steps++;
+                if (ROWS) lossfrac = (lossfrac + before) - s[7];
             }
             NXC_STAMP(1);                              // step + fate
             fresh = false;
             const bool live = s[7] > 0.0;
+            if (ROWS && live) {
+                if (k < nrow) store_record(rec, row0 + k, s, lossfrac, id);
+                else my_overrun++;                     // the two passes disagree: reported, never written
+            }
             if (IMAGE && live) {
                 my_samples++;
                 p = image_locate(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], rv, fw,
@@ -512,6 +488,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         }
     }
     flush_counter(&ctr->particle_steps, my_steps);
+    if (ROWS) flush_counter(&ctr->unfinished, my_overrun);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
         flush_counter(&ctr->samples_binned, my_binned);
@@ -678,19 +655,21 @@ struct LosK {
     double sin_dphi, sin_2dphi, cos_thr, cos_thr2_lo, vrplanet, unit_cm2;
     double log1p_s_inv, t0;        // ladder: t_k = t0 (1 + sin_dphi)^k; only to seed the ball search
     int n_lines, n_ladder;
+    int64_t index_shift;           // subtracted from the index column: packet number inside its Output
     int64_t tile_off;              // byte offset of the spectra tile inside the LDS block
     LutDesc line[4];
 };
 
 constexpr int NXC_LOS_TILE = 128;  // spectra per workgroup tile (8 doubles each)
 
-// T: double, or float for samples as Output.save() stores them (widened exactly, like restore())
-template <typename T>
+// T: double, or float for samples as Output.save() stores them (widened exactly, like restore());
+// I: the type of the packet-index column (int64, or int32 as save() stores it)
+template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
       const double *__restrict__ sc, int64_t P, const T *__restrict__ x,
       const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ vy,
-      const T *__restrict__ frac, const long long *__restrict__ index,
+      const T *__restrict__ frac, const I *__restrict__ index,
       const double *__restrict__ ladder, double *__restrict__ radiance,
       unsigned long long *__restrict__ npackets, unsigned char *__restrict__ included,
       long long used_cap, long long *__restrict__ used_pairs,
@@ -758,7 +737,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             if (wtemp != 0.0) unsafeAtomicAdd(&radiance[i], wtemp);
             atomicAdd(&npackets[i], 1ull);
             my_pairs++;
-            if (included) included[index ? index[p] : p] = 1;
+            if (included) included[index ? (long long)index[p] - K.index_shift : p] = 1;
             if (used_pairs && wtemp > 0.0) {
                 const unsigned long long slot = atomicAdd(n_used, 1ull);
                 if ((long long)slot < used_cap) {

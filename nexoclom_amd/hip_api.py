@@ -28,7 +28,9 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_los_accumulate_f32', 'nxc_packets_sample',
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
-           'nxc_allreduce_sum_f64')
+           'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
+           'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows')
+ABI_VERSION = 2
 
 
 class HipError(RuntimeError):
@@ -105,8 +107,9 @@ def load_library():
     lib.nxc_last_error_string.restype = C.c_char_p
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError here = ABI mismatch
-    if lib.nxc_abi_version() != 1:
-        raise HipError('libnexoclom_hip.so ABI version mismatch')
+    if lib.nxc_abi_version() != ABI_VERSION:
+        raise HipError(f'libnexoclom_hip.so has ABI version {lib.nxc_abi_version()}, this binding '
+                       f'is written for {ABI_VERSION}: rebuild with `python -m nexoclom_amd.build`')
     _lib = lib
     return lib
 
@@ -126,6 +129,46 @@ def device_count():
     if rc != 0:
         return 0
     return n.value
+
+
+class RowStore:
+    """Compact trajectory rows that stay in HBM (an ``nxc_rows``): the nine columns time, x, y, z,
+    vx, vy, vz, frac, lossfrac and the packet-index column of ``total`` live records, float32 /
+    int32 when ``narrow`` (what the reference's save() stores) or float64 / int64.  Views of it
+    (row ranges) feed the image and line-of-sight kernels without touching the host."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._r = ctx, handle
+        total, f32 = C.c_int64(0), C.c_int32(0)
+        ctx._check(ctx.lib.nxc_rows_info(handle, C.byref(total), C.byref(f32)))
+        self.total, self.narrow = int(total.value), bool(f32.value)
+
+    @property
+    def nbytes(self):
+        return self.total * (9*4 + 4 if self.narrow else 9*8 + 8)
+
+    def download(self, first=0, count=None, index=True):
+        """(rows (9, count), index (count,) | None) of the row range as host arrays."""
+        count = self.total - first if count is None else int(count)
+        rows = np.empty((9, count), dtype=np.float32 if self.narrow else np.float64)
+        idx = np.empty(count, dtype=np.int32 if self.narrow else np.int64) if index else None
+        if self._r is None:
+            raise HipError('the row store has been freed')
+        self.ctx._check(self.ctx.lib.nxc_rows_download(
+            self.ctx._h, self._r, C.c_int64(first), C.c_int64(count),
+            rows.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p) if index else None))
+        return rows, idx
+
+    def free(self):
+        if self._r is not None and getattr(self.ctx, '_h', None):
+            self.ctx.lib.nxc_rows_free(self.ctx._h, self._r)
+        self._r = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -361,16 +404,21 @@ class Context:
         return dict(traj=traj, final=None if final is None else np.ascontiguousarray(final.T),
                     steps=steps)
 
-    def integrate_const_rows(self, step, n_iter, outeredge, narrow=False):
+    def integrate_const_rows(self, step, n_iter, outeredge, narrow=False, resident=False):
         """Trajectories as Output.save() keeps them: only the records with frac > 0,
         packet-major.  Returns dict(lengths (N,) int64, rows (9, total): the 8 state columns and
-        lossfrac); narrow=True delivers them as float32 (save()'s down-cast, done on the device)."""
+        lossfrac); narrow=True delivers them as float32 (save()'s down-cast, done on the device).
+        resident=True leaves them in HBM instead: dict(lengths, store: RowStore)."""
         n = self.n_packets
         lengths = np.empty(n, dtype=np.int64)
         total = C.c_int64(0)
         self._check(self.lib.nxc_integrate_const_rows(
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             lengths.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total)))
+        if resident:
+            handle = C.c_void_p()
+            self._check(self.lib.nxc_rows_build(self._h, C.c_int(int(narrow)), C.byref(handle)))
+            return dict(lengths=lengths, store=RowStore(self, handle))
         rows = np.empty((9, int(total.value)), dtype=np.float32 if narrow else np.float64)
         if narrow:
             self._check(self.lib.nxc_rows_fetch_f32(
@@ -407,11 +455,22 @@ class Context:
         self._check(self.lib.nxc_image_accumulate(self._h, C.c_int64(len(x)), _p(x), _p(y), _p(z),
                                                   _p(vy), _p(frac)))
 
+    def image_accumulate_rows(self, store, first=0, count=None):
+        """Bin rows [first, first + count) of a RowStore: no host round trip."""
+        count = store.total - first if count is None else int(count)
+        if store._r is None:
+            raise HipError('the row store has been freed')
+        self._check(self.lib.nxc_image_accumulate_rows(self._h, store._r, C.c_int64(first),
+                                                       C.c_int64(count)))
+
     # -- f-1: spacecraft lines of sight ------------------------------------------------------
     def los_accumulate(self, dphi, sin_dphi, sin_2dphi, cos_threshold, vrplanet, unit_cm, g_tables,
-                       ladder, sc, x, y, z, vy, frac, index=None, n_index=0, used_cap=0):
-        """sc: (8, S) array x,y,z,xbore,ybore,zbore,dist_from_plan,ladder_len.  Returns
-        dict(radiance, npackets, included|None, used (2, m)|None, n_used)."""
+                       ladder, sc, x=None, y=None, z=None, vy=None, frac=None, index=None,
+                       n_index=0, used_cap=0, rows=None):
+        """sc: (8, S) array x,y,z,xbore,ybore,zbore,dist_from_plan,ladder_len.  Samples: five host
+        columns (+ index), or ``rows = (RowStore, first, count, index_shift)`` for rows that are
+        already in HBM.  Returns dict(radiance, npackets, included|None, used (2, m)|None,
+        n_used)."""
         d = nxc_los_desc()
         d.dphi, d.sin_dphi, d.sin_2dphi, d.cos_threshold = dphi, sin_dphi, sin_2dphi, cos_threshold
         d.vrplanet, d.unit_cm = float(vrplanet), float(unit_cm)
@@ -425,6 +484,27 @@ class Context:
         d.n_ladder, d.ladder = len(lad), _p(lad)
         sc = _f64(sc)
         S = sc.shape[1]
+        if rows is not None:
+            store, first, count, shift = rows
+            if store._r is None:
+                raise HipError('the row store has been freed')
+            radiance = np.zeros(S)
+            npackets = np.zeros(S, dtype=np.int64)
+            included = np.zeros(n_index, dtype=np.uint8) if n_index else None
+            used = np.zeros((2, used_cap), dtype=np.int64) if used_cap else None
+            n_used = C.c_int64(0)
+            i64p = C.POINTER(C.c_int64)
+            self._check(self.lib.nxc_los_accumulate_rows(
+                self._h, C.byref(d), C.c_int64(S), _p(sc), store._r, C.c_int64(first),
+                C.c_int64(count), C.c_int64(shift), C.c_int64(n_index), _p(radiance),
+                npackets.ctypes.data_as(i64p),
+                included.ctypes.data_as(C.POINTER(C.c_uint8)) if included is not None else None,
+                C.c_int64(used_cap), used.ctypes.data_as(i64p) if used is not None else None,
+                C.byref(n_used)))
+            m = min(int(n_used.value), used_cap)
+            return dict(radiance=radiance, npackets=npackets,
+                        included=None if included is None else included.astype(bool),
+                        used=None if used is None else used[:, :m], n_used=int(n_used.value))
         cols = (x, y, z, vy, frac)
         narrow = all(getattr(c, 'dtype', None) == np.float32 for c in cols)
         if narrow:          # stored float32 samples go over as they are; the device widens them

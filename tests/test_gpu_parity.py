@@ -348,3 +348,50 @@ def test_lookup_table_equals_np_interp_on_adversarial_tables(ctx, seed):
     assert keep.sum() > 100000
     assert np.array_equal(a[:, 1], want, equal_nan=True)
     assert np.array_equal(a[:, 0], np.zeros(m)) and np.array_equal(ion, np.zeros(m))
+
+
+@pytest.mark.parametrize('narrow', [False, True])
+def test_resident_rows_equal_the_fetched_rows_and_feed_the_image(ctx, narrow):
+    """nxc_rows_build keeps pass 2's rows in HBM: what comes back through nxc_rows_download (whole
+    store and a row range) is what nxc_rows_fetch[_f32] delivers, the index column is the packet
+    number of every row (the reference's X.Index, Output.py:438), and nxc_image_accumulate_rows
+    over the store gives the image of the same columns sent from the host."""
+    f = H.mercury_forces('Na', 1.3)
+    endtime, step = 9000., 30.
+    n = 5000
+    X0 = H.sample_x0(n, 33, endtime)
+    X0[::23, 7] = 0.0
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None)
+    ctx.upload_packets(X0)
+    fetched = ctx.integrate_const_rows(step, n_iter, 8.0, narrow=narrow)
+    res = ctx.integrate_const_rows(step, n_iter, 8.0, narrow=narrow, resident=True)
+    assert ctx.counters()['unfinished'] == 0
+    store = res['store']
+    assert store.total == fetched['rows'].shape[1] == res['lengths'].sum() and store.narrow == narrow
+    rows, index = store.download()
+    assert rows.dtype == fetched['rows'].dtype and np.array_equal(rows, fetched['rows'])
+    assert index.dtype == (np.int32 if narrow else np.int64)
+    assert np.array_equal(index, np.repeat(np.arange(n), res['lengths']))
+    part, pidx = store.download(1234, 40000)
+    assert np.array_equal(part, rows[:, 1234:41234]) and np.array_equal(pidx, index[1234:41234])
+    # the image of rows [a, b) from HBM == the image of the same columns sent from the host
+    im = H.image_setup(f, 'radiance', dims=(96, 96))
+    a, b = 777, store.total - 999
+    for src in ('host', 'store'):
+        ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                      im['g_tables'])
+        if src == 'host':
+            ctx.image_accumulate(*(rows[c, a:b] for c in (1, 2, 3, 5, 7)))
+            want, want_counts = ctx.image_download()
+            want_ctr = ctx.counters()
+        else:
+            ctx.image_accumulate_rows(store, a, b - a)
+            got, got_counts = ctx.image_download()
+            assert ctx.counters() == want_ctr
+    assert want_counts.sum() > 1e5 and np.array_equal(got_counts, want_counts)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    store.free()
+    with pytest.raises(Exception):
+        store.download()
