@@ -118,6 +118,7 @@ int nxc_destroy(nxc_handle *h);
 int nxc_device_name(nxc_handle *h, char *buf, int buflen);
 int nxc_device_bus_id(nxc_handle *h, char *buf, int buflen);  /* PCI bus id, e.g. "0000:05:00.0" */
 int nxc_synchronize(nxc_handle *h);
+int nxc_mem_info(nxc_handle *h, uint64_t *free_bytes, uint64_t *total_bytes);  /* device memory */
 
 /* ---- set-up ---------------------------------------------------------------------------------- */
 int nxc_set_forces(nxc_handle *h, const nxc_forces *f);
@@ -288,7 +289,9 @@ int nxc_rows_fetch_f32(nxc_handle *h, float *rows_out);
  * ModelImage / LOSResult (ModelImage.py:85-98, LOSResult.py:264-266), minus the disk and the
  * host.  Stores are freed explicitly; a handle may own any number of them.
  *   nxc_rows_download          rows [first, first + count) -> cols_out host [9][count] (nullable)
- *                              and index_out host [count] (nullable), in the store's types
+ *                              and index_out host [count] (nullable), in the store's types; runs on
+ *                              a stream of its own and may be called from a second host thread
+ *                              (a file writer) while the handle's thread computes
  *   nxc_image_accumulate_rows  create_image over those rows (columns x, y, z, vy, frac), as
  *                              nxc_image_accumulate[_f32] without the host round trip
  *   nxc_los_accumulate_rows    compute_iteration over those rows, as nxc_los_accumulate[_f32];

@@ -55,6 +55,13 @@ class Input:
     def _sections(self):
         return [getattr(self, name) for name, _ in SECTIONS]
 
+    def __copy__(self):
+        # a copy shares the catalogue (ModelResult copies its inputs) but not the writer thread
+        new = type(self).__new__(type(self))
+        new.__dict__.update({k: v for k, v in self.__dict__.items()
+                             if k not in ('_writer', '_pending')})
+        return new
+
     def __eq__(self, other):
         return isinstance(other, type(self)) and self._sections() == other._sections()
 
@@ -79,6 +86,7 @@ class Input:
     def delete_files(self, filename=None):
         """Forget (and remove from disk) every catalogued run, or only the one saved as
         ``filename`` (Input.py:274-...)."""
+        self.wait()
         doomed = [run for run in self._catalogue if filename is None or run.filename == filename]
         for run in doomed:
             if run.filename and os.path.exists(run.filename):
@@ -100,7 +108,7 @@ class Input:
 
     def run(self, npackets, packs_per_it=None, overwrite=False, compress=True,
             distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None,
-            sampler='numpy'):
+            sampler='numpy', batch=True):
         """Integrate until the catalogue holds ``npackets`` packets (Input.py:175-268).
 
         Every pass plans ``ceil(todo / size)`` Outputs of ``size = min(todo, chunk_size)``
@@ -109,7 +117,13 @@ class Input:
         reference's stream; the reference itself passes the same seed to every Output
         (Input.py:246), which repeats identical packets.  ``sampler='device'`` draws the initial
         states on the GPU instead (counter-based: the k-th Output continues the index space of
-        the ones before it under the one ``seed``)."""
+        the ones before it under the one ``seed``).
+
+        The Outputs of a pass are independent, so they are INTEGRATED TOGETHER (``batch``): one
+        upload, one launch of each kernel over all their packets (Output.integrate_batch), each
+        Output then owning its slice of the rows, which stay in HBM for produce_image /
+        LOSResult.  With a ``savepath`` the files are written by a worker thread beside the next
+        launch (``wait()`` joins it)."""
         from .Output import Output
         started = time.time()
         if distribute in (True, 'delay', 'delayed'):
@@ -120,27 +134,83 @@ class Input:
         want = int(npackets)
         made = 0
         drawn = have                             # device sampler: next free global packet index
+        # re-emission draws are keyed by (the Output's seed, the packet's number): host-sampled
+        # Outputs each have their own seed, so with re-emission they cannot share a launch
+        spec = self.surfaceinteraction
+        sticks = spec.sticktype == 'constant' and spec.stickcoef == 1.
+        together = bool(batch) and keep_trajectory and (compress or self.options.step_size == 0) \
+            and not (sampler == 'device' and self.options.step_size == 0) \
+            and (sticks or sampler == 'device')
+        if together and context is None:
+            from . import hip_api
+            context = hip_api.Context(device)
         while have < want:
             todo = want - have
             size = min(todo, self.chunk_size(packs_per_it))
             passes = -(-todo // size)
             print('Running Model')
             print(f'Will complete {passes} iterations of {size} packets.')
-            for number in range(1, passes + 1):
-                print(f'Starting iteration #{number} of {passes}')
+            number = 0
+            while number < passes:
                 tick = time.time()
-                if sampler == 'device':
-                    draw = dict(seed=seed, sampler='device', first_index=drawn)
-                else:
-                    draw = dict(seed=None if seed is None else seed + made)
-                out = Output(self, size, compress=compress, device=device,
-                             keep_trajectory=keep_trajectory, context=context, **draw)
-                drawn += size
-                context = out.context()          # every Output of the run shares one device
-                made += 1
+                # as many Outputs per launch as HBM takes (rows: nsteps records per packet at most,
+                # far fewer in practice; the row store spills its oldest runs to the host)
+                group = min(passes - number, self._group_limit(size, context)) if together else 1
+                outs = []
+                for g in range(group):
+                    number += 1
+                    print(f'Starting iteration #{number} of {passes}')
+                    if sampler == 'device':
+                        draw = dict(seed=seed, sampler='device', first_index=drawn,
+                                    presampled=together, materialize_x0=not together)
+                    else:
+                        draw = dict(seed=None if seed is None else seed + made)
+                    out = Output(self, size, compress=compress, device=device,
+                                 keep_trajectory=keep_trajectory, context=context,
+                                 integrate=not together, save=not together, **draw)
+                    context = out.context()      # every Output of the run shares one device
+                    outs.append(out)
+                    drawn += size
+                    made += 1
+                if together and outs:
+                    if sampler == 'device':
+                        lead = outs[0]
+                        soa = context.sample_packets(size*len(outs), 0 if seed is None else seed,
+                                                     lead._first_index, download=True,
+                                                     **lead.source_desc())
+                        for g, out in enumerate(outs):
+                            out._adopt_x0(soa[:, g*size:(g + 1)*size])
+                    Output.integrate_batch(outs, context)
                 print(f'Completed iteration #{number} in {time.time() - tick} seconds.')
             have = self._report()
+        self.wait()                              # files of this run are on disk when it returns
         print(f'Model run completed in {time.time() - started:.2f} sec.')
+
+    def _group_limit(self, size, context):
+        """How many Outputs of ``size`` packets one launch may take: the packets' states and a
+        generous estimate of their rows (a quarter of the dense history) within a third of the
+        device's free memory; at least one."""
+        step = self.options.step_size
+        per_packet = 8*8*3
+        if step != 0:
+            records = int(math.ceil(self.options.endtime.value/step) + 1)
+            per_packet += records*80//4
+        free, _ = context.mem_info()
+        return max(1, int(free//3//(per_packet*size)))
+
+    # ---- files in the background ------------------------------------------------------------
+    def _write_later(self, job, *args):
+        """Run ``job(*args)`` on the writer thread (one at a time, in order)."""
+        if getattr(self, '_writer', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._writer, self._pending = ThreadPoolExecutor(max_workers=1), []
+        self._pending.append(self._writer.submit(job, *args))
+
+    def wait(self):
+        """Block until every file of the catalogue is on disk; re-raises a writer's error."""
+        pending, self._pending = getattr(self, '_pending', []), []
+        for job in pending:
+            job.result()
 
     def _report(self):
         _, files, packets, _ = self.search()

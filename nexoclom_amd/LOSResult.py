@@ -127,7 +127,7 @@ class LOSResult(ModelResult):
         from .Output import Output
         if not isinstance(output, Output):       # a file; a catalogued Output is used as stored:
             output = Output.restore(output)      # the binding widens just the columns it sends
-        samples, spectra = output.X, scdata.data
+        spectra = scdata.data
         if self._geometry is None or self._geometry[0] is not spectra:
             # the same for every Output of a run (compute_iteration.py recomputes it per file)
             self._geometry = (spectra, los_geometry(spectra, self.inputs.options.outeredge,
@@ -135,17 +135,26 @@ class LOSResult(ModelResult):
         cut, lengths, ladder = self._geometry[1]
         sc = np.vstack([spectra[list(POSITION + BORESIGHT)].values.T.astype(float), cut,
                         lengths.astype(float)])
-        if 'Index' in samples.columns:
-            index = samples['Index'].values
+        setup = (self.dphi, np.sin(self.dphi), np.sin(self.dphi*2), arccos_threshold(self.dphi),
+                 float(output.vrplanet)/self.unit_km, self.unit_km*1e5,
+                 self.g_tables(float(output.aplanet)), ladder, sc)
+        view = output.resident_rows(self.context())
+        if view is not None:
+            # the Output's rows are still in HBM: no host round trip
+            store, first, count, packet0 = view
+            res = self.context().los_accumulate(*setup, n_index=int(output.npackets),
+                                                used_cap=used_cap,
+                                                rows=(store, first, count, packet0))
         else:
-            index = np.arange(len(samples))
-        n_index = int(len(output.X0)) if len(output.X0) else int(index.max()) + 1
-        res = self.context().los_accumulate(
-            self.dphi, np.sin(self.dphi), np.sin(self.dphi*2), arccos_threshold(self.dphi),
-            float(output.vrplanet)/self.unit_km, self.unit_km*1e5,
-            self.g_tables(float(output.aplanet)), ladder, sc,
-            *(samples[c].values for c in ('x', 'y', 'z', 'vy', 'frac')),
-            index=index, n_index=n_index, used_cap=used_cap)
+            samples = output.X
+            if 'Index' in samples.columns:
+                index = samples['Index'].values
+            else:
+                index = np.arange(len(samples))
+            n_index = int(len(output.X0)) if len(output.X0) else int(index.max()) + 1
+            res = self.context().los_accumulate(
+                *setup, *(samples[c].values for c in ('x', 'y', 'z', 'vy', 'frac')),
+                index=index, n_index=n_index, used_cap=used_cap)
         assert self.context().counters()['nonfinite'] == 0, 'Non-finite weights'
         res['totalsource'] = output.totalsource
         for key in ('radiance', 'npackets'):

@@ -229,14 +229,21 @@ class ModelImage(ModelResult):
         """ModelImage.py:229-274 for one catalogued Output (or .npz path): the restored sample
         columns are rotated, masked, weighted and binned inside one HIP kernel."""
         from .Output import Output
-        samples, aplanet, vrplanet_kms = Output.image_columns(output)
-        if samples is None or len(samples[0]) == 0:
-            raise ValueError('this Output holds no trajectory (it was run with '
-                             'keep_trajectory=False); use ModelImage(..., npackets=N) instead')
         ctx = self.context()
-        vr = vrplanet_kms/self.unit_km                     # km/s -> R/s (ModelImage.py:242-243)
-        self._set_image(ctx, aplanet, vr, downcast=False)
-        ctx.image_accumulate(*samples)
+        view = output.resident_rows(ctx) if isinstance(output, Output) else None
+        if view is not None and view[2] > 0:
+            # the rows are still in HBM as save() would have stored them: bin them where they are
+            aplanet, vrplanet_kms = float(output.aplanet), float(output.vrplanet)
+            self._set_image(ctx, aplanet, vrplanet_kms/self.unit_km, downcast=False)
+            ctx.image_accumulate_rows(view[0], view[1], view[2])
+        else:
+            samples, aplanet, vrplanet_kms = Output.image_columns(output)
+            if samples is None or len(samples[0]) == 0:
+                raise ValueError('this Output holds no trajectory (it was run with '
+                                 'keep_trajectory=False); use ModelImage(..., npackets=N) instead')
+            vr = vrplanet_kms/self.unit_km                 # km/s -> R/s (ModelImage.py:242-243)
+            self._set_image(ctx, aplanet, vr, downcast=False)
+            ctx.image_accumulate(*samples)
         self.counters = ctx.counters()
         assert self.counters['nonfinite'] == 0, 'Non-finite weights'
         image, counts = ctx.image_download()

@@ -19,6 +19,10 @@ loss_info, randgen, compress, inputs, planet) and the same column order of ``X``
   GPU, statistically equivalent, for runs where host sampling would dominate),
   ``first_index`` (offset of this chunk in the device sampler's counter space) and
   ``materialize_x0`` (False: leave the device-sampled states on the GPU).
+* the trajectory rows of a constant-step run stay in HBM (hip_api.RowStore) in exactly the form
+  save() would store them -- frac > 0 rows, float32 / int32 -- and ``X`` is built from them on
+  first access; ModelImage and LOSResult read the resident rows directly.  ``Output.integrate_batch``
+  integrates several Outputs of one ``Input.run`` in a single launch.
 """
 import os
 
@@ -49,14 +53,20 @@ def n_output_steps(endtime, step):
 
 
 class Output:
+    # trajectory rows resident on the device (a view of a hip_api.RowStore) until X is asked for
+    _X = None
+    _store = None
+    _row0 = _nrows = _packet0 = 0
+    _lengths = None
+
     def __init__(self, inputs, npackets, compress=True, run_model=True, seed=None, *,
                  device=0, integrate=True, keep_trajectory=True, context=None, save=True,
-                 sampler='numpy', first_index=0, materialize_x0=True):
+                 sampler='numpy', first_index=0, materialize_x0=True, presampled=False):
         self.inputs = inputs
         self.planet = inputs.geometry.planet
         # a finished reference Output always went through save() (Output.py:202): its frames are
         # 32-bit.  When this one will too, the rows can leave the device already narrowed.
-        self._narrow_rows = bool(save and integrate and run_model)
+        self._narrow_rows = bool(save and run_model)
         self._ctx = context
         self._device = device
         self.filename = None
@@ -128,13 +138,14 @@ class Output:
             if sampler == 'device':
                 if inputs.geometry.planet.object != inputs.geometry.startpoint:
                     raise NotImplementedError("sampler='device' launches from the planet only")
-                soa = self.context().sample_packets(
+                # presampled: the caller drew this Output's packets as part of a larger device call
+                # (Input.run takes all its chunks in one go)
+                soa = None if presampled else self.context().sample_packets(
                     npackets, 0 if seed is None else seed, first_index,
                     download=materialize_x0, **self.source_desc())
-                self._resident = True
-                if materialize_x0:
-                    self.X0 = pd.DataFrame({c: soa[k] for k, c in enumerate(STATE_COLS)})
-                    self.X0['v'] = np.sqrt(self.X0.vx**2 + self.X0.vy**2 + self.X0.vz**2)
+                self._resident = not presampled
+                if materialize_x0 and not presampled:
+                    self._adopt_x0(soa)
                 else:
                     self.X0 = pd.DataFrame()
             elif sampler == 'numpy':
@@ -293,6 +304,11 @@ class Output:
         X0['vx'] = (c*vxl - s_*vyl) - aw*c - mo['omega']*yr
         X0['vy'] = (s_*vxl + c*vyl) - aw*s_ + mo['omega']*xr
 
+    def _adopt_x0(self, soa):
+        """X0 of a device-sampled Output from its (8, n) block of the downloaded states."""
+        self.X0 = pd.DataFrame({c: soa[k] for k, c in enumerate(STATE_COLS)})
+        self.X0['v'] = np.sqrt(self.X0.vx**2 + self.X0.vy**2 + self.X0.vz**2)
+
     def upload(self, ctx):
         """Make this Output's initial states the context's resident packet set."""
         if getattr(self, '_resident', False) and ctx is self._ctx:
@@ -309,42 +325,83 @@ class Output:
         assert ctr.get('neg_frac', 0) == 0, 'Found new values of frac that are negative'
         assert ctr.get('bad_step', 0) == 0, 'Bad step size'
 
+    # ---- X: built from the resident rows on first access ------------------------------------
+    @property
+    def X(self):
+        if self._X is None and self._store is not None:
+            self._X = self._frame_from_rows()
+        return self._X
+
+    @X.setter
+    def X(self, frame):
+        self._X = frame
+
+    def _attach_rows(self, store, row0, lengths, packet0):
+        """This Output's trajectories are rows [row0, row0 + sum(lengths)) of ``store``; its
+        packets are numbers packet0 .. packet0 + npackets - 1 of the store's index column."""
+        self._store, self._row0, self._packet0 = store, int(row0), int(packet0)
+        self._lengths = lengths
+        self._nrows = int(lengths.sum())
+        self._X = None
+        store.owners.add(self)
+
+    def resident_rows(self, ctx=None):
+        """(store, first row, row count, first packet) while the rows live in HBM (on ``ctx``'s
+        device when given), else None."""
+        store = self._store
+        if store is None or store._r is None or (ctx is not None and store.ctx is not ctx):
+            return None
+        return store, self._row0, self._nrows, self._packet0
+
+    def _host_rows(self):
+        """(rows (9, n), Index (n,)) of this Output as save() stores them, from HBM."""
+        rows, idx = self._store.download(self._row0, self._nrows)
+        if self._packet0:
+            idx -= idx.dtype.type(self._packet0)
+        return rows, idx
+
+    def _frame_from_rows(self):
+        """The reference's X after save()'s frac > 0 filter (Output.py:435-449,523-524): the
+        surviving rows keep their original labels packet*nsteps + ct."""
+        rows, idx = self._host_rows()
+        n, lengths = self.npackets, self._lengths
+        starts = np.cumsum(lengths) - lengths
+        labels = np.repeat(np.arange(n, dtype=np.int64)*self.nsteps - starts, lengths)
+        labels += np.arange(len(labels), dtype=np.int64)
+        columns = {'Index': idx}
+        columns.update((name, rows[k]) for k, name in enumerate(STATE_COLS))
+        columns['lossfrac'] = rows[8]
+        return pd.DataFrame(columns, index=pd.Index(labels), copy=False)   # one frame, no copies
+
+    def _spill(self):
+        """Called before the store is evicted from HBM: keep the rows on the host instead."""
+        if self._store is not None:
+            if self._X is None:
+                self._X = self._frame_from_rows()
+            self._store = None
+
     # ---- drivers --------------------------------------------------------------------------
+    def _device_setup(self, ctx):
+        ctx.set_forces(**self.forces_kwargs())
+        ctx.set_bounce(self._bounce)
+        ctx.set_bodies(self._bodies)
+        ctx.set_first_index(self._first_index)
+
     def constant_step_size_driver(self, keep_trajectory=True):
-        """Output.py:368-455 on the GPU.  With keep_trajectory the lock-step kernel returns every
-        record and ``X`` is assembled exactly like the reference's (N*nsteps rows, columns
-        Index,time,x,y,z,vx,vy,vz,frac,lossfrac).  lossfrac starts from 0 (the reference's
-        starts from uninitialised memory, Output.py:378)."""
+        """Output.py:368-455 on the GPU.  compress=True (the default): the trajectories stay in
+        HBM as the rows save() keeps (frac > 0, Output.py:523-524) and ``X`` is assembled from
+        them on first access; compress=False: the dense (N*nsteps rows) frame of the reference,
+        columns Index,time,x,y,z,vx,vy,vz,frac,lossfrac.  lossfrac starts from 0 (the
+        reference's starts from uninitialised memory, Output.py:378)."""
         opt = self.inputs.options
         endtime, step = opt.endtime.value, float(opt.step_size)
         self.nsteps, n_iter = n_output_steps(endtime, step)
         ctx = self.context()
-        ctx.set_forces(**self.forces_kwargs())
+        self._device_setup(ctx)
         self.upload(ctx)
-        ctx.set_bounce(self._bounce)
-        ctx.set_bodies(self._bodies)
-        ctx.set_first_index(self._first_index)
         n = self.npackets
         if keep_trajectory and self.compress:
-            # compress=True keeps only the rows with frac > 0 (Output.py:523-524, applied by the
-            # save() every reference Output ends in): the kernel delivers exactly those rows,
-            # packet-major like the filtered frame, instead of the >90 % zero-padded dense array
-            res = ctx.integrate_const_rows(step, n_iter, opt.outeredge, narrow=self._narrow_rows)
-            ctr = ctx.counters()
-            self._raise_on_counters(ctr)
-            assert ctr.get('unfinished', 0) == 0, 'row passes disagree'
-            rows, lengths = res['rows'], res['lengths']
-            # the frac > 0 filter leaves the surviving rows' original labels (packet*nsteps + ct)
-            starts = np.cumsum(lengths) - lengths
-            labels = np.repeat(np.arange(n, dtype=np.int64)*self.nsteps - starts, lengths)
-            labels += np.arange(len(labels), dtype=np.int64)
-            index = np.repeat(np.arange(n, dtype=np.int32 if self._narrow_rows else np.int64),
-                              lengths)
-            columns = {'Index': index}
-            columns.update((name, rows[k]) for k, name in enumerate(STATE_COLS))
-            columns['lossfrac'] = rows[8]
-            X = pd.DataFrame(columns, index=pd.Index(labels), copy=False)   # one frame, no copies
-            self.X = X
+            self._rows_pass(ctx, [self], step, n_iter)
         elif keep_trajectory:
             res = ctx.integrate_const(step, n_iter, opt.outeredge, nrec=self.nsteps)
             self._raise_on_counters(ctx.counters())
@@ -371,6 +428,27 @@ class Output:
         self.totalsource *= self.nsteps                      # Output.py:434
         self._add_units()
 
+    @staticmethod
+    def _rows_pass(ctx, outputs, step, n_iter):
+        """The compact-rows protocol over the context's resident packets, which are the packets
+        of ``outputs`` one Output after the other: the kernel delivers exactly the rows with
+        frac > 0, packet-major like the reference's filtered frame, and they stay in HBM; each
+        Output gets its slice."""
+        lead = outputs[0]
+        res = ctx.integrate_const_rows(step, n_iter, lead.inputs.options.outeredge,
+                                       narrow=lead._narrow_rows, resident=True)
+        ctr = ctx.counters()
+        lengths, store = res['lengths'], res['store']
+        row0 = packet0 = 0
+        for out in outputs:
+            out._raise_on_counters(ctr)
+            assert ctr.get('unfinished', 0) == 0, 'row passes disagree'
+            mine = lengths[packet0:packet0 + out.npackets]
+            out._attach_rows(store, row0, mine, packet0)
+            row0 += out._nrows
+            packet0 += out.npackets
+        assert row0 == store.total and packet0 == len(lengths)
+
     def variable_step_size_driver(self):
         """Output.py:221-366 on the GPU: final snapshot, one row per packet."""
         opt = self.inputs.options
@@ -380,7 +458,9 @@ class Output:
         ctx.set_bodies(None)
         ctx.upload_soa(np.ascontiguousarray(self.X[STATE_COLS].values.T, dtype=np.float64))
         final, hs = ctx.integrate_var(float(opt.resolution), opt.outeredge)
-        ctr = ctx.counters()
+        self._finish_variable(ctx.counters(), final, hs)
+
+    def _finish_variable(self, ctr, final, hs):
         self._raise_on_counters(ctr)
         assert ctr.get('unfinished', 0) == 0, 'variable-step integration did not finish'
         for k, name in enumerate(STATE_COLS):
@@ -388,6 +468,50 @@ class Output:
         self.X['step_size'] = hs
         self.X['Index'] = self.X.index
         self._add_units()
+
+    @classmethod
+    def integrate_batch(cls, outputs, ctx, save=True):
+        """Integrate several Outputs of the same inputs (built with ``integrate=False``) in ONE
+        device launch: packets are independent, so the chunks of an Input.run (Input.py:243-246)
+        only differ in which rows of the result they own.  The kernels' queue then holds all the
+        chunks' packets and the long-lived ones of every chunk start first, which is what keeps
+        the lanes busy (one reference-sized chunk alone has fewer packets than the chip has
+        lanes).  Results are identical to integrating the Outputs one by one."""
+        lead = outputs[0]
+        opt = lead.inputs.options
+        for out in outputs:
+            out._ctx = ctx
+            out._narrow_rows = bool(save)
+        if opt.step_size == 0:
+            print('Running variable step size integrator.')
+            for out in outputs:
+                out.X = out.X0.drop(['longitude', 'latitude', 'local_time'], axis=1)
+                out.X['lossfrac'] = np.zeros(out.npackets)
+                assert out._bounce is None, 'Not set up'
+            ctx.set_forces(**lead.forces_kwargs())
+            ctx.set_bodies(None)
+            ctx.upload_soa(np.concatenate([out.x0_soa() for out in outputs], axis=1))
+            final, hs = ctx.integrate_var(float(opt.resolution), opt.outeredge)
+            ctr, at = ctx.counters(), 0
+            for out in outputs:
+                out._finish_variable(ctr, final[at:at + out.npackets], hs[at:at + out.npackets])
+                at += out.npackets
+        else:
+            print('Running constant step size integrator.')
+            endtime, step = opt.endtime.value, float(opt.step_size)
+            nsteps, n_iter = n_output_steps(endtime, step)
+            lead._device_setup(ctx)
+            if not all(getattr(out, '_resident', False) or out.sampler == 'device'
+                       for out in outputs):
+                ctx.upload_soa(np.concatenate([out.x0_soa() for out in outputs], axis=1))
+            cls._rows_pass(ctx, outputs, step, n_iter)
+            for out in outputs:
+                out.nsteps = nsteps
+                out.totalsource *= nsteps                    # Output.py:434
+                out._add_units()
+        if save:
+            for out in outputs:
+                out.save()
 
     def _add_units(self):
         # Output.py:363-366,452-455: aplanet in au, vrplanet in km/s, GM in R^3/s^2
@@ -403,12 +527,16 @@ class Output:
     # ---- persistence (file catalogue instead of PostgreSQL + pickle) ------------------------
     def save(self):
         """Apply the reference's on-disk transformations (compress filter, 32-bit down-cast,
-        Output.py:522-543), register in the inputs' catalogue, optionally write an .npz."""
-        if self.compress and len(self.X) > 0 and 'frac' in self.X:
-            keep = self.X.frac.values > 0
-            if not keep.all():          # the compact-rows path already delivers only these rows
-                self.X = self.X[keep]
-        self.X0, self.X = self._recast(self.X0, NARROW), self._recast(self.X, NARROW)
+        Output.py:522-543), register in the inputs' catalogue, optionally write an .npz.  Rows
+        that came from the compact-rows kernels are already filtered (on the 64-bit frac, like
+        the reference: a float32 underflow of frac must not drop a row) and narrowed."""
+        if self._store is None or self._X is not None:
+            if self._store is None and self.compress and len(self.X) > 0 and 'frac' in self.X:
+                keep = self.X.frac.values > 0
+                if not keep.all():
+                    self.X = self.X[keep]
+            self.X = self._recast(self.X, NARROW)
+        self.X0 = self._recast(self.X0, NARROW)
         catalogue = getattr(self.inputs, '_catalogue', None)
         if catalogue is not None:
             self.idnum = len(catalogue) + 1
@@ -416,12 +544,24 @@ class Output:
             if savepath:
                 os.makedirs(savepath, exist_ok=True)
                 self.filename = os.path.join(savepath, f'{self.idnum:010d}.npz')
-                self._write(self.filename)
+                submit = getattr(self.inputs, '_write_later', None)
+                if submit is not None and self._store is not None:
+                    submit(self._write, self.filename)   # D2H + file I/O beside the next launch
+                else:
+                    self._write(self.filename)
             catalogue.append(self)
 
     def _write(self, filename):
         data = {f'X0.{c}': self.X0[c].values for c in self.X0}
-        data.update({f'X.{c}': self.X[c].values for c in self.X})
+        if self._X is None and self._store is not None:
+            # straight from HBM (own copy stream; possibly on the writer thread): the frame itself
+            # is not built for a file
+            rows, idx = self._host_rows()
+            data['X.Index'] = idx
+            data.update({f'X.{c}': rows[k] for k, c in enumerate(STATE_COLS)})
+            data['X.lossfrac'] = rows[8]
+        else:
+            data.update({f'X.{c}': self.X[c].values for c in self.X})
         np.savez(filename, npackets=self.npackets, totalsource=self.totalsource,
                  nsteps=self.nsteps or 0, aplanet=float(self.aplanet),
                  vrplanet_kms=float(self.vrplanet), compress=self.compress, **data)

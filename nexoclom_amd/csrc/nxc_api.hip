@@ -245,6 +245,7 @@ struct nxc_handle {
     int device = 0;
     int n_cu = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // row-store downloads: run beside the compute stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     char name[256] = {0};
@@ -288,6 +289,10 @@ struct nxc_handle {
     size_t samples_cap = 0;
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
+    unsigned long long *d_hist = nullptr;   // counting-sort bins of the queue order
+    size_t hist_cap = 0;
+    void *d_rec = nullptr;           // pass 2's records on their way to columns (grow-only)
+    size_t rec_cap = 0;
 
     // compact-rows protocol (nxc_integrate_const_rows -> nxc_rows_fetch)
     long long *d_offsets = nullptr;
@@ -305,6 +310,9 @@ struct nxc_handle {
     int rank = 0, nranks = 1;
     double *d_reduce = nullptr;      // one double for control-plane reductions
 };
+
+static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifetimes,
+                           int64_t max_steps);
 
 namespace {
 
@@ -530,11 +538,11 @@ size_t persist_lds_rows(size_t table_bytes)
     return ((table_bytes + 31) & ~size_t(31)) + (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES_ROWS;
 }
 
-template <bool BOUNCE, bool FULL, bool NBODY>
-int launch_rows(nxc_handle *h, int64_t n_iter, double edge2, double *d_rec)
+template <bool BOUNCE, bool FULL, bool NBODY, int ROWS>
+int launch_rows(nxc_handle *h, int64_t n_iter, double edge2, void *d_rec)
 {
     int grid = 1, block = BLOCK_PERSIST, rc;
-    auto kernel = k_const_fused<false, BOUNCE, FULL, NBODY, true>;
+    auto kernel = k_const_fused<false, BOUNCE, FULL, NBODY, ROWS>;
     const size_t tables = h->force_bytes, lds = persist_lds_rows(tables);
     if ((rc = prep_kernel(kernel, lds))) return rc;
     if ((rc = persistent_grid(h, kernel, &block, lds, h->n_packets, &grid))) return rc;
@@ -584,57 +592,54 @@ int count_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge, boo
     HIPCHK(hipMemcpyAsync(h->d_offsets, off.data(), ((size_t)n + 1) * sizeof(long long),
                           hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    // the lifetimes are now known exactly: re-sort the queue by them (longest first) for pass 2
+    // and for every later pass over these packets
+    if ((rc = order_on_device(h, 0.0, h->d_steps, n_iter))) return rc;
     h->rows_total = acc;
     h->rows_step = step; h->rows_edge = outeredge; h->rows_n_iter = n_iter; h->rows_n = n;
     *total_out = acc;
     return NXC_OK;
 }
 
-// Pass 2: the records themselves, rec[total][10] in device memory (*d_rec_out, caller frees).
-// `reserve`: bytes the caller is about to allocate next to it (checked against free memory).
-int write_records(nxc_handle *h, size_t reserve, double **d_rec_out)
+// Pass 2: the records themselves, rec[total][10] (doubles, or floats + int32 when narrow) in the
+// handle's record scratch.  `reserve`: bytes the caller is about to allocate next to it (checked
+// against free memory).
+int write_records(nxc_handle *h, bool narrow, size_t reserve)
 {
     int rc = need_forces(h);
     if (rc) return rc;
-    *d_rec_out = nullptr;
     if (h->rows_total < 0 || h->rows_n != h->n_packets)
         return fail(NXC_ERR_STATE, "the trajectory rows need a preceding nxc_integrate_const_rows");
     const long long total = h->rows_total;
     if (total == 0) return NXC_OK;
-    const size_t bytes = (size_t)total * NXC_REC_DOUBLES * sizeof(double);
+    const size_t bytes = (size_t)total * 10 * (narrow ? sizeof(float) : sizeof(double));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if (bytes + reserve > free_b)
+    if ((bytes > h->rec_cap ? bytes : 0) + reserve > free_b + (bytes > h->rec_cap ? h->rec_cap : 0))
         return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
                                  "per call (the reference chunks too, Input.py:219-222)");
+    if ((rc = ensure(&h->d_rec, &h->rec_cap, bytes))) return rc;
     if (h->have_bodies) {
         if (h->have_bounce)
             return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
         if ((rc = upload_moon_table(h, h->rows_step, h->rows_n_iter))) return rc;
     }
-    double *d_rec = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d_rec), bytes));
-    rc = upload_step(h, h->rows_step);
-    if (!rc && hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream) != hipSuccess)
-        rc = fail(NXC_ERR_HIP, "hipMemsetAsync(counters) failed");
-    if (!rc) {
-        const double edge2 = sqrt_threshold(h->rows_edge);
-        const int64_t n_iter = h->rows_n_iter;
-        const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
-        if (h->have_bodies)
-            rc = full ? launch_rows<false, true, true>(h, n_iter, edge2, d_rec)
-                      : launch_rows<false, false, true>(h, n_iter, edge2, d_rec);
-        else if (h->have_bounce) rc = launch_rows<true, false, false>(h, n_iter, edge2, d_rec);
-        else rc = full ? launch_rows<false, true, false>(h, n_iter, edge2, d_rec)
-                       : launch_rows<false, false, false>(h, n_iter, edge2, d_rec);
-    }
-    if (rc) { (void)hipFree(d_rec); return rc; }
-    *d_rec_out = d_rec;
-    return NXC_OK;
+    if ((rc = upload_step(h, h->rows_step))) return rc;
+    HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+    const double edge2 = sqrt_threshold(h->rows_edge);
+    const int64_t n_iter = h->rows_n_iter;
+    const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
+#define NXC_ROWS_CASE(B, F, N)                                                                  \
+    (narrow ? launch_rows<B, F, N, 2>(h, n_iter, edge2, h->d_rec)                               \
+            : launch_rows<B, F, N, 1>(h, n_iter, edge2, h->d_rec))
+    if (h->have_bodies) return full ? NXC_ROWS_CASE(false, true, true) : NXC_ROWS_CASE(false, false, true);
+    if (h->have_bounce) return NXC_ROWS_CASE(true, false, false);
+    return full ? NXC_ROWS_CASE(false, true, false) : NXC_ROWS_CASE(false, false, false);
+#undef NXC_ROWS_CASE
 }
 
 template <typename T, typename I>
-int transpose_rows(nxc_handle *h, const double *d_rec, long long total, void *d_cols, void *d_index)
+int transpose_rows(nxc_handle *h, const void *d_rec, long long total, void *d_cols, void *d_index)
 {
     int64_t g = (total + NXC_TR_ROWS - 1) / NXC_TR_ROWS;
     const int64_t cap = (int64_t)h->n_cu * 16;
@@ -654,23 +659,21 @@ int rows_build(nxc_handle *h, bool narrow, nxc_rows **out)
     const size_t vsz = narrow ? sizeof(float) : sizeof(double), isz = narrow ? sizeof(int) : sizeof(long long);
     const size_t cols_bytes = (size_t)(total > 0 ? total : 0) * 9 * vsz;
     const size_t idx_bytes = (size_t)(total > 0 ? total : 0) * isz;
-    double *d_rec = nullptr;
-    int rc = write_records(h, cols_bytes + idx_bytes, &d_rec);
+    int rc = write_records(h, narrow, cols_bytes + idx_bytes);
     if (rc) return rc;
     h->rows_total = -1;
     nxc_rows *r = new (std::nothrow) nxc_rows();
-    if (!r) { (void)hipFree(d_rec); return fail(NXC_ERR_ARG, "out of host memory"); }
+    if (!r) return fail(NXC_ERR_ARG, "out of host memory");
     r->device = h->device; r->f32 = narrow; r->total = total;
     hipError_t e = hipSuccess;
     if (total > 0) {
         e = hipMalloc(&r->d_cols, cols_bytes);
         if (e == hipSuccess) e = hipMalloc(&r->d_index, idx_bytes);
         if (e == hipSuccess)
-            rc = narrow ? transpose_rows<float, int>(h, d_rec, total, r->d_cols, r->d_index)
-                        : transpose_rows<double, long long>(h, d_rec, total, r->d_cols, r->d_index);
+            rc = narrow ? transpose_rows<float, int>(h, h->d_rec, total, r->d_cols, r->d_index)
+                        : transpose_rows<double, long long>(h, h->d_rec, total, r->d_cols, r->d_index);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
     }
-    (void)hipFree(d_rec);
     if (e != hipSuccess || rc) {
         if (r->d_cols) (void)hipFree(r->d_cols);
         if (r->d_index) (void)hipFree(r->d_index);
@@ -922,6 +925,7 @@ int nxc_create(int device, nxc_handle **out)
     std::snprintf(h->name, sizeof h->name, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
                   prop.multiProcessorCount);
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&h->d_ctr), sizeof(DevCounters));
@@ -944,11 +948,12 @@ int nxc_destroy(nxc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
-                    h->d_source, h->d_queue, h->d_samples};
+                    h->d_source, h->d_queue, h->d_samples, h->d_hist, h->d_rec};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NXC_OK;
@@ -965,6 +970,17 @@ int nxc_device_bus_id(nxc_handle *h, char *buf, int buflen)
 {
     if (!h || !buf || buflen < 16) return fail(NXC_ERR_ARG, "bad arguments");
     HIPCHK(hipDeviceGetPCIBusId(buf, buflen, h->device));
+    return NXC_OK;
+}
+
+int nxc_mem_info(nxc_handle *h, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
     return NXC_OK;
 }
 
@@ -1301,32 +1317,45 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
 // Queue order of the resident packets, built on the device: counting sort of the packet indices
 // by decreasing |v|^2 (k_order_hist / k_order_scatter).  k2max: upper bound of |v|^2 when the
 // caller knows it (the sampler does), negative = find the largest finite |v|^2 on the device.
-static int order_on_device(nxc_handle *h, double k2max)
+// d_lifetimes != null: sort by those step counts instead (exact lifetimes from a counting pass;
+// max_steps = their upper bound).
+static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifetimes,
+                           int64_t max_steps)
 {
     const int64_t n = h->n_packets;
-    h->have_order = false;
-    if (n >= 2 && k2max < 0) {
-        unsigned long long bits = 0;
-        unsigned long long *d_max = reinterpret_cast<unsigned long long *>(h->d_reduce);
-        HIPCHK(hipMemsetAsync(d_max, 0, sizeof bits, h->stream));
-        hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
-                           h->stream, h->d_packets, n, d_max);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof bits, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        std::memcpy(&k2max, &bits, sizeof k2max);
+    const bool by_steps = d_lifetimes != nullptr;
+    if (by_steps) {
+        if (n < 2 || n >= (int64_t)0xffffffffll || max_steps < 1) return NXC_OK;   // keep what there is
+    } else {
+        h->have_order = false;
+        if (n >= 2 && k2max < 0) {
+            unsigned long long bits = 0;
+            unsigned long long *d_max = reinterpret_cast<unsigned long long *>(h->d_reduce);
+            HIPCHK(hipMemsetAsync(d_max, 0, sizeof bits, h->stream));
+            hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+                               h->stream, h->d_packets, n, d_max);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof bits, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            std::memcpy(&k2max, &bits, sizeof k2max);
+        }
+        if (n < 2 || n >= (int64_t)0xffffffffll || !(k2max > 0) || !std::isfinite(k2max)) return NXC_OK;
     }
-    if (n < 2 || n >= (int64_t)0xffffffffll || !(k2max > 0) || !std::isfinite(k2max)) return NXC_OK;
     int rc = ensure(reinterpret_cast<void **>(&h->d_order), &h->order_cap, (size_t)n * sizeof(unsigned));
     if (rc) return rc;
     const size_t hb = (size_t)NXC_ORDER_BINS * sizeof(unsigned long long);
-    if ((rc = ensure(reinterpret_cast<void **>(&h->d_steps), &h->steps_cap, hb))) return rc;
-    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(h->d_steps);
-    const double scale = (double)(NXC_ORDER_BINS - 1) / k2max;
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_hist), &h->hist_cap, hb))) return rc;
+    unsigned long long *d_hist = h->d_hist;
+    const double scale = by_steps ? (double)(NXC_ORDER_BINS - 1) / (double)max_steps
+                                  : (double)(NXC_ORDER_BINS - 1) / k2max;
     HIPCHK(hipMemsetAsync(d_hist, 0, hb, h->stream));
     const int grid = flat_grid(h, n, NXC_BLOCK);
-    hipLaunchKernelGGL(k_order_hist, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
-                       scale, d_hist);
+    if (by_steps)
+        hipLaunchKernelGGL(k_order_hist<true>, dim3(grid), dim3(NXC_BLOCK), 0, h->stream,
+                           h->d_packets, d_lifetimes, n, scale, d_hist);
+    else
+        hipLaunchKernelGGL(k_order_hist<false>, dim3(grid), dim3(NXC_BLOCK), 0, h->stream,
+                           h->d_packets, d_lifetimes, n, scale, d_hist);
     HIPCHK(hipGetLastError());
     std::vector<unsigned long long> hist(NXC_ORDER_BINS), start(NXC_ORDER_BINS);
     HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hb, hipMemcpyDeviceToHost, h->stream));
@@ -1335,8 +1364,13 @@ static int order_on_device(nxc_handle *h, double k2max)
     for (int b = 0; b < NXC_ORDER_BINS; b++) { start[b] = acc; acc += hist[b]; }
     if (acc != (unsigned long long)n) return fail(NXC_ERR_HIP, "order histogram lost packets");
     HIPCHK(hipMemcpyAsync(d_hist, start.data(), hb, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_order_scatter, dim3(grid), dim3(NXC_BLOCK), 0, h->stream, h->d_packets, n,
-                       scale, d_hist, h->d_order);
+    h->have_order = false;
+    if (by_steps)
+        hipLaunchKernelGGL(k_order_scatter<true>, dim3(grid), dim3(NXC_BLOCK), 0, h->stream,
+                           h->d_packets, d_lifetimes, n, scale, d_hist, h->d_order);
+    else
+        hipLaunchKernelGGL(k_order_scatter<false>, dim3(grid), dim3(NXC_BLOCK), 0, h->stream,
+                           h->d_packets, d_lifetimes, n, scale, d_hist, h->d_order);
     HIPCHK(hipGetLastError());
     // the persistent kernels read the queue front to back: give them a contiguous copy
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_queue), &h->queue_cap,
@@ -1364,7 +1398,7 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     h->rows_total = -1;
     // Queue order for the persistent kernels (longest-lived first): counting sort of the packet
     // indices by decreasing |v|^2 on the device, bounded by the largest launch speed found there.
-    if ((rc = order_on_device(h, -1.0))) return rc;
+    if ((rc = order_on_device(h, -1.0, nullptr, 0))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
     });
@@ -1450,7 +1484,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
                                    : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
     }
-    if ((rc = order_on_device(h, vmax * vmax))) return rc;
+    if ((rc = order_on_device(h, vmax * vmax, nullptr, 0))) return rc;
     if (soa_out) HIPCHK(hipMemcpyAsync(soa_out, h->d_packets, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
@@ -1519,9 +1553,9 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         HIPCHK(hipStreamSynchronize(h->stream));
         d_final = h->d_scratch;
         d_steps = h->d_steps;
-        double *d_rec = nullptr;
-        if ((rc = write_records(h, tbytes, &d_rec))) return rc;
+        if ((rc = write_records(h, false, tbytes))) return rc;
         h->rows_total = -1;
+        const double *d_rec = static_cast<const double *>(h->d_rec);
         double *d_traj = nullptr;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_traj), tbytes);
         if (e == hipSuccess) {
@@ -1544,7 +1578,6 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         }
         if (d_traj) (void)hipFree(d_traj);
-        if (d_rec) (void)hipFree(d_rec);
         if (e != hipSuccess)
             return fail(NXC_ERR_HIP, std::string("trajectory run: ") + hipGetErrorString(e));
     }
@@ -1596,6 +1629,7 @@ int nxc_rows_free(nxc_handle *h, nxc_rows *r)
     if (!r) return NXC_OK;
     (void)hipSetDevice(r->device);
     if (h && h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (r->d_cols) (void)hipFree(r->d_cols);
     if (r->d_index) (void)hipFree(r->d_index);
     delete r;
@@ -1610,16 +1644,20 @@ int nxc_rows_download(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t c
     if (rc) return rc;
     if (count == 0) return NXC_OK;
     HIPCHK(hipSetDevice(h->device));
+    // a finished store is immutable (nxc_rows_build synchronises before it returns), so the copy
+    // goes on its own stream and may be issued from a second host thread (a file writer) while
+    // the handle's thread launches the next run
+    hipStream_t st = h->copy_stream;
     const size_t vsz = r->f32 ? 4 : 8, isz = r->f32 ? 4 : 8;
     if (cols_out)          // nine strided column pieces -> [9][count]
         HIPCHK(hipMemcpy2DAsync(cols_out, (size_t)count * vsz,
                                 static_cast<const char *>(r->d_cols) + (size_t)first * vsz,
                                 (size_t)r->total * vsz, (size_t)count * vsz, 9,
-                                hipMemcpyDeviceToHost, h->stream));
+                                hipMemcpyDeviceToHost, st));
     if (index_out)
         HIPCHK(hipMemcpyAsync(index_out, static_cast<const char *>(r->d_index) + (size_t)first * isz,
-                              (size_t)count * isz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+                              (size_t)count * isz, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return NXC_OK;
     });
 }

@@ -170,40 +170,65 @@ k_rk5_step(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes
 // aligned 16-byte stores per record; a 128-byte line is completed by two consecutive steps of
 // one lane), and k_rows_transpose turns the finished block into the columns the host wants
 // (struct-of-arrays, optionally narrowed to float32 / int32: save()'s down-cast, Output.py:528-543).
+// ROWS = 1: records of ten doubles; ROWS = 2: the same record narrowed on the way out (nine floats
+// and an int32: save()'s down-cast, Output.py:528-543, which every catalogued Output goes
+// through) -- half the store requests and half the bytes the transposition has to read.
 constexpr int NXC_REC_DOUBLES = 10;
+constexpr int NXC_REC_FLOATS = 10;
+typedef float nxc_v4f __attribute__((ext_vector_type(4)));
+typedef float nxc_v2f __attribute__((ext_vector_type(2)));
+typedef float nxc_v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
-NXC_DEV void store_record(double *__restrict__ rec, long long row, const double (&s)[8],
+template <int ROWS>
+NXC_DEV void store_record(void *__restrict__ rec, long long row, const double (&s)[8],
                           double lossfrac, long long id)
 {
-    nxc_v2d *p = reinterpret_cast<nxc_v2d *>(rec + row * NXC_REC_DOUBLES);   // 16-byte aligned
-    nxc_v2d a, b, c, d, e;
-    a.x = s[0]; a.y = s[1]; b.x = s[2]; b.y = s[3]; c.x = s[4]; c.y = s[5]; d.x = s[6]; d.y = s[7];
-    e.x = lossfrac; e.y = __longlong_as_double(id);
-    p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e;
+    if (ROWS == 2) {
+        float *p = static_cast<float *>(rec) + row * NXC_REC_FLOATS;        // 8-byte aligned
+        nxc_v4f a, b;
+        nxc_v2f c;
+        a.x = (float)s[0]; a.y = (float)s[1]; a.z = (float)s[2]; a.w = (float)s[3];
+        b.x = (float)s[4]; b.y = (float)s[5]; b.z = (float)s[6]; b.w = (float)s[7];
+        c.x = (float)lossfrac; c.y = __int_as_float((int)id);
+        *reinterpret_cast<nxc_v4f_a8 *>(p) = a;
+        *reinterpret_cast<nxc_v4f_a8 *>(p + 4) = b;
+        *reinterpret_cast<nxc_v2f *>(p + 8) = c;
+    } else {
+        nxc_v2d *p = reinterpret_cast<nxc_v2d *>(static_cast<double *>(rec) + row * NXC_REC_DOUBLES);
+        nxc_v2d a, b, c, d, e;                                              // 16-byte aligned
+        a.x = s[0]; a.y = s[1]; b.x = s[2]; b.y = s[3]; c.x = s[4]; c.y = s[5]; d.x = s[6]; d.y = s[7];
+        e.x = lossfrac; e.y = __longlong_as_double(id);
+        p[0] = a; p[1] = b; p[2] = c; p[3] = d; p[4] = e;
+    }
 }
 
-// rec[total][10] -> cols[9][total] and index[total]; T = double | float,
-// I = long long | int.  A block moves 256 records through LDS: coalesced 16-byte reads, coalesced
-// column writes.
+// rec[total][10] -> cols[9][total] and index[total].  <double, long long>: fp64 records to fp64 /
+// int64 columns; <float, int>: narrowed records to float32 / int32 columns.  A block moves 256
+// records through LDS: coalesced 8-byte reads, coalesced column writes.
 constexpr int NXC_TR_ROWS = 256;
 template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_TR_ROWS)
-k_rows_transpose(const double *__restrict__ rec, long long total, T *__restrict__ cols,
+k_rows_transpose(const void *__restrict__ rec_, long long total, T *__restrict__ cols,
                  I *__restrict__ index)
 {
-    __shared__ nxc_v2d tile[NXC_TR_ROWS * NXC_REC_DOUBLES / 2];
+    static_assert(sizeof(T) == sizeof(I), "a record is ten equal-sized slots");
+    typedef T pair_t __attribute__((ext_vector_type(2)));
+    __shared__ pair_t tile[NXC_TR_ROWS * 5];
+    const T *rec = static_cast<const T *>(rec_);
     for (long long base = (long long)blockIdx.x * NXC_TR_ROWS; base < total;
          base += (long long)gridDim.x * NXC_TR_ROWS) {
         const int nrow = (int)((total - base) < NXC_TR_ROWS ? (total - base) : NXC_TR_ROWS);
-        const nxc_v2d *src = reinterpret_cast<const nxc_v2d *>(rec + base * NXC_REC_DOUBLES);
-        for (int w = threadIdx.x; w < nrow * (NXC_REC_DOUBLES / 2); w += NXC_TR_ROWS) tile[w] = src[w];
+        const pair_t *src = reinterpret_cast<const pair_t *>(rec + base * 10);
+        for (int w = threadIdx.x; w < nrow * 5; w += NXC_TR_ROWS) tile[w] = src[w];
         __syncthreads();
         if ((int)threadIdx.x < nrow) {
-            const double *r = reinterpret_cast<const double *>(tile) + threadIdx.x * NXC_REC_DOUBLES;
+            const T *r = reinterpret_cast<const T *>(tile) + threadIdx.x * 10;
             const long long row = base + threadIdx.x;
 #pragma unroll
-            for (int c = 0; c < 9; c++) cols[c * total + row] = (T)r[c];
-            index[row] = (I)__double_as_longlong(r[9]);
+            for (int c = 0; c < 9; c++) cols[c * total + row] = r[c];
+            I id;
+            __builtin_memcpy(&id, &r[9], sizeof id);
+            index[row] = id;
         }
         __syncthreads();
     }
@@ -332,10 +357,10 @@ struct WaveQueue {
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
-// ROWS (never with IMAGE): every live record -- the initial state and the state after each step
-// while frac > 0 -- goes to row offsets[id] + k of rec[total][10] with lossfrac accumulated as
+// ROWS != 0 (never with IMAGE): every live record -- the initial state and the state after each step
+// while frac > 0 -- goes to row offsets[id] + k of rec[total][10] (doubles, or floats for ROWS = 2) with lossfrac accumulated as
 // (lossfrac + frac_before) - frac_after per step (Output.py:420-421) from 0.
-template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, bool ROWS = false>
+template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, int ROWS = 0>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
@@ -343,7 +368,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ acc2,
               DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr,
-              const long long *__restrict__ offsets = nullptr, double *__restrict__ rec = nullptr)
+              const long long *__restrict__ offsets = nullptr, void *__restrict__ rec = nullptr)
 {
     static_assert(!(IMAGE && ROWS), "the rows pass has no image");
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n,
@@ -381,7 +406,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = nxc_stamp();
 #endif
     for (;;) {
-        const long long got = q.refill<ROWS>(!has, stage_off, s, &row0, &nrow);
+        const long long got = q.refill<ROWS != 0>(!has, stage_off, s, &row0, &nrow);
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; lossfrac = 0.0; }
         if (__ballot(has) == 0) break;
         NXC_STAMP(0);                                  // refill
@@ -425,7 +450,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             fresh = false;
             const bool live = s[7] > 0.0;
             if (ROWS && live) {
-                if (k < nrow) store_record(rec, row0 + k, s, lossfrac, id);
+                if (k < nrow) store_record<ROWS>(rec, row0 + k, s, lossfrac, id);
                 else my_overrun++;                     // the two passes disagree: reported, never written
             }
             if (IMAGE && live) {
@@ -879,6 +904,16 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict
 // Queue order on the device: counting sort of the packet indices by decreasing |v|^2.
 constexpr int NXC_ORDER_BINS = 4096;
 
+// BY_STEPS: the key is the packet's known number of steps (after a counting pass the lifetimes are
+// exact, so the queue becomes longest-processing-time-first proper and the lanes of a wave, which
+// hold neighbours of the sorted order, finish together).
+NXC_DEV int steps_bin(const long long *__restrict__ steps, int64_t i, double scale)
+{
+    const double f = (double)steps[i] * scale;
+    int b = f < (double)NXC_ORDER_BINS ? (int)f : NXC_ORDER_BINS - 1;
+    return NXC_ORDER_BINS - 1 - (b < 0 ? 0 : b);
+}
+
 NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t n, int64_t i, double scale)
 {
     const double vx = soa[4 * n + i], vy = soa[5 * n + i], vz = soa[6 * n + i];
@@ -908,16 +943,17 @@ k_speed_max(const double *__restrict__ soa, int64_t n, unsigned long long *__res
         atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
 
+template <bool BY_STEPS>
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_order_hist(const double *__restrict__ soa, int64_t n, double scale,
-             unsigned long long *__restrict__ hist)
+k_order_hist(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t n,
+             double scale, unsigned long long *__restrict__ hist)
 {
     __shared__ unsigned lh[NXC_ORDER_BINS];
     for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x) lh[b] = 0;
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&lh[speed_bin(soa, n, i, scale)], 1u);
+        atomicAdd(&lh[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, n, i, scale)], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
         if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
@@ -936,13 +972,15 @@ k_order_gather(const double *__restrict__ soa, int64_t n, const unsigned *__rest
     }
 }
 
+template <bool BY_STEPS>
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_order_scatter(const double *__restrict__ soa, int64_t n, double scale,
-                unsigned long long *__restrict__ cursor, unsigned *__restrict__ order)
+k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t n,
+                double scale, unsigned long long *__restrict__ cursor, unsigned *__restrict__ order)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long pos = atomicAdd(&cursor[speed_bin(soa, n, i, scale)], 1ull);
+        const unsigned long long pos =
+            atomicAdd(&cursor[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, n, i, scale)], 1ull);
         order[pos] = (unsigned)i;
     }
 }

@@ -5,6 +5,7 @@ entry point raises.  Arrays cross the boundary as C-contiguous float64 NumPy buf
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -29,7 +30,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
-           'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows')
+           'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info')
 ABI_VERSION = 2
 
 
@@ -139,6 +140,7 @@ class RowStore:
 
     def __init__(self, ctx, handle):
         self.ctx, self._r = ctx, handle
+        self.owners = weakref.WeakSet()       # the Outputs whose rows these are
         total, f32 = C.c_int64(0), C.c_int32(0)
         ctx._check(ctx.lib.nxc_rows_info(handle, C.byref(total), C.byref(f32)))
         self.total, self.narrow = int(total.value), bool(f32.value)
@@ -164,6 +166,12 @@ class RowStore:
             self.ctx.lib.nxc_rows_free(self.ctx._h, self._r)
         self._r = None
 
+    def spill(self):
+        """Leave HBM: every owner first takes its rows to the host."""
+        for owner in list(self.owners):
+            owner._spill()
+        self.free()
+
     def __del__(self):
         try:
             self.free()
@@ -181,6 +189,7 @@ class Context:
         self.device = device
         self.n_packets = 0
         self.image_shape = None
+        self._stores = []              # resident RowStores, oldest first (weak references)
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc):
@@ -188,7 +197,20 @@ class Context:
             msg = self.lib.nxc_last_error_string()
             raise HipError(f'nexoclom_hip error {rc}: {msg.decode() if msg else "?"}')
 
+    def make_room(self, need):
+        """Before ``need`` bytes of row store (+ scratch) are allocated: spill the oldest resident
+        stores to their owners' host memory until they fit (their Outputs keep working from the
+        host copy)."""
+        alive = [ref for ref in self._stores if ref() is not None and ref()._r is not None]
+        self._stores = alive
+        while alive and self.mem_info()[0] < need + (1 << 30):
+            alive.pop(0)().spill()
+
     def close(self):
+        for ref in getattr(self, '_stores', ()):
+            store = ref()
+            if store is not None:
+                store.free()
         if getattr(self, '_h', None) is not None and self._h:
             self.lib.nxc_destroy(self._h)
             self._h = C.c_void_p()
@@ -217,6 +239,12 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.nxc_synchronize(self._h))
+
+    def mem_info(self):
+        """(free, total) bytes of device memory."""
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.nxc_mem_info(self._h, C.byref(free), C.byref(total)))
+        return int(free.value), int(total.value)
 
     # -- set-up -----------------------------------------------------------------------------
     def set_forces(self, GM, vrplanet, gravity=True, radpres=True, lifetime=0.0, photo=None,
@@ -416,9 +444,13 @@ class Context:
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             lengths.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(total)))
         if resident:
+            # records on their way (10 slots) + the columns that stay (9 + index)
+            self.make_room(int(total.value) * 20 * (4 if narrow else 8))
             handle = C.c_void_p()
             self._check(self.lib.nxc_rows_build(self._h, C.c_int(int(narrow)), C.byref(handle)))
-            return dict(lengths=lengths, store=RowStore(self, handle))
+            store = RowStore(self, handle)
+            self._stores.append(weakref.ref(store))
+            return dict(lengths=lengths, store=store)
         rows = np.empty((9, int(total.value)), dtype=np.float32 if narrow else np.float64)
         if narrow:
             self._check(self.lib.nxc_rows_fetch_f32(

@@ -496,3 +496,50 @@ def test_device_sampler_refuses_unusable_tables(ctx):
     # a usable call afterwards still works on the same handle
     X = ctx.sample_packets(1000, 1, download=True, **src)
     assert np.isfinite(X).all() and np.allclose(np.linalg.norm(X[1:4], axis=0), 1.0)
+
+
+@pytest.mark.parametrize('mode', ['constant', 'variable', 'device-sampled'])
+def test_batched_input_run_equals_output_by_output(ctx, mode, tmp_path):
+    """Input.run integrates the Outputs of a pass in ONE launch (Output.integrate_batch) and
+    leaves their rows in HBM: every Output must hold exactly what it holds when the Outputs are
+    integrated one by one (batch=False) -- frames, labels, dtypes, totals -- the image built from
+    the resident rows must be the image built from the host frames, and the files written by the
+    worker thread must restore to the same frames."""
+    def make(batch, savepath=None):
+        inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'), savepath=savepath)
+        inputs.options.endtime = type(inputs.options.endtime)(9000., 's')
+        if mode == 'variable':
+            inputs.options.step_size = 0.
+            inputs.options.resolution = 1e-4
+        with contextlib.redirect_stdout(io.StringIO()):
+            inputs.run(4200, packs_per_it=1000, seed=9, context=ctx, batch=batch,
+                       sampler='device' if mode == 'device-sampled' else 'numpy')
+        return inputs
+    one, many = make(False), make(True, str(tmp_path))
+    assert len(one._catalogue) == len(many._catalogue) == 5
+    for a, b in zip(one._catalogue, many._catalogue):
+        if mode != 'variable':
+            assert b.resident_rows(ctx) is not None and b._X is None       # nothing on the host yet
+        assert a.totalsource == b.totalsource and a.nsteps == b.nsteps and a.idnum == b.idnum
+        assert list(a.X.columns) == list(b.X.columns)
+        assert np.array_equal(a.X.index.values, b.X.index.values)
+        for c in a.X.columns:
+            assert a.X[c].dtype == b.X[c].dtype, c
+            assert np.array_equal(a.X[c].values, b.X[c].values), c
+        for c in a.X0.columns:
+            assert np.array_equal(a.X0[c].values, b.X0[c].values), c
+        back = Output.restore(b.filename)
+        for c in ('x', 'vy', 'frac', 'Index'):
+            assert np.array_equal(back.X[c].values, b.X[c].values.astype(back.X[c].dtype)), c
+    if mode != 'variable':
+        params = {'quantity': 'radiance', 'dims': '64,64'}
+        resident = many.produce_image(params, context=ctx)       # rows read in HBM
+        for b in many._catalogue:
+            b._spill()                                           # now from the host frames
+            assert b.resident_rows(ctx) is None
+        host = many.produce_image(params, context=ctx)
+        assert resident.packet_image.sum() > 1000
+        assert np.array_equal(resident.packet_image, host.packet_image)
+        np.testing.assert_allclose(resident.image, host.image, rtol=1e-12, atol=0)
+        one_img = one.produce_image(params, context=ctx)
+        assert np.array_equal(one_img.packet_image, host.packet_image)

@@ -3,8 +3,8 @@
 
   k_image        a-6..a-8  stored samples -> image (40 B/sample radiance, 32 B column)
   k_var          a-4       adaptive-step driver (128 B per rk5 attempt)
-  k_const_rows   a-3/f-3   compact trajectory rows (72 B written per live record)
-  k_const_traj   a-3       dense trajectory (64 B written per record slot)
+  k_const_fused<ROWS>  a-3/f-3   compact trajectory rows (72 B per live record) -- one chunk and
+                       the 13 chunks of Input.run(1e6) in one launch; the dense trajectory
   k_los          f-1       line-of-sight cones ((spectrum, sample) pair tests)
   k_sample       f-4       initial states on the device (64 B written per packet)
   k_speed_max / k_order_hist / k_order_scatter   queue order of the resident packets
@@ -73,20 +73,53 @@ def main():
     ctx.set_bounce(None); ctx.set_bodies(None)
     ctx.upload_soa(out.x0_soa())
     for _ in range(reps):
-        res = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge)
-        ms_rows = ctx.last_kernel_ms()
-    rows = res['rows']
-    P = rows.shape[1]
-    line('k_const_rows', ms_rows, P, 'live records written', 72,
-         f'{n} packets (one reference chunk), {P} live records of {n*nsteps} slots; the kernel '
-         f're-integrates the packets ({ctx.counters()["particle_steps"]} particle-steps)')
+        t0 = time.perf_counter()
+        res = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge, narrow=True,
+                                       resident=True)
+        call_ms = (time.perf_counter() - t0)*1e3
+        ms_rows = ctx.last_kernel_ms()          # pass 2: k_const_fused<ROWS>
+        store = res['store']
+        P = store.total
+        rows = store.download(index=False)[0]
+        store.free()
+    work = ctx.counters()["particle_steps"]
+    line('k_const_fused<ROWS> one chunk', ms_rows, P, 'live records written', 72,
+         f'{n} packets (ONE reference chunk: fewer packets than the chip has lanes, so the launch '
+         f'lasts as long as its longest packet), {P} live records of {n*nsteps} slots, {work} '
+         f'particle-steps re-integrated; whole resident call (pass 1, offsets, pass 2, '
+         f'transpose to float32 columns) {call_ms:.2f} ms')
+    # all 13 chunks of Input.run(1e6) (Input.py:216-246) in ONE launch, as Input.run does here
+    nchunks = 13
+    with quiet():
+        many = [Output(inputs, n, seed=1 + k, integrate=False, save=False, context=ctx).x0_soa()
+                for k in range(nchunks)]
+    ctx.upload_soa(np.concatenate(many, axis=1))
+    del many
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge, narrow=True,
+                                       resident=True)
+        call_ms = (time.perf_counter() - t0)*1e3
+        ms_batch = ctx.last_kernel_ms()
+        Pb = res['store'].total
+        res['store'].free()
+    workb = ctx.counters()["particle_steps"]
+    line(f'k_const_fused<ROWS> {nchunks} chunks in one launch', ms_batch, Pb,
+         'live records written', 72,
+         f'{nchunks} x {n} packets, {Pb} live records, {workb} particle-steps; per reference chunk '
+         f'{ms_batch/nchunks:.3f} ms; whole resident call {call_ms:.2f} ms '
+         f'({call_ms/nchunks:.2f} per chunk)')
     nt = 20000
     ctx.upload_soa(np.ascontiguousarray(out.x0_soa()[:, :nt]))
     for _ in range(reps):
+        t0 = time.perf_counter()
         ctx.integrate_const(opt.step_size, n_iter, opt.outeredge, nrec=nsteps)
+        call_ms = (time.perf_counter() - t0)*1e3
         ms_traj = ctx.last_kernel_ms()
-    line('k_const_traj', ms_traj, nt*nsteps, 'record slots', 64,
-         f'{nt} packets x {nsteps} records, dense (compress=False)')
+    line('dense trajectory: k_const_fused<ROWS> + k_rows_densify', ms_traj, nt*nsteps,
+         'record slots', 64,
+         f'{nt} packets x {nsteps} records, dense (compress=False); kernel_ms = the rows pass; '
+         f'whole call incl. the {8*nt*nsteps*8/1e9:.2f} GB device-to-host copy {call_ms:.1f} ms')
 
     x, y, z, vy, frac = (np.ascontiguousarray(rows[c]) for c in (1, 2, 3, 5, 7))
     # replicate the samples to a bench-sized stream (the image kernel is linear in the samples)

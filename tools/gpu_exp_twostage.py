@@ -28,12 +28,27 @@ import shutil; shutil.rmtree(tmp)
 
 # the reference's own user flow at 1e6 packets: Input.run (chunked like Input.py:219-222, every
 # chunk catalogued with its trajectory) then Input.produce_image
+import contextlib, io, cProfile, pstats
+for rep in range(2):
+    inputs = Input(infile)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(1e6, seed=7, context=ctx)
+    t1 = time.time()
+    img = inputs.produce_image({'quantity': 'radiance', 'dims': '512,512'}, context=ctx)
+    t2 = time.time()
+    rows = sum(o._nrows for o in inputs._catalogue)
+    print(f'Input.run(1e6): {t1-t0:.3f}s in {len(inputs._catalogue)} chunks, {rows:.3e} rows resident '
+          f'in HBM; produce_image {t2-t1:.3f}s; total {t2-t0:.3f}s', flush=True)
+    t3 = time.time()
+    X = inputs._catalogue[0].X
+    t4 = time.time()
+    print(f'   first access to one Output.X ({len(X):.3e} rows): {t4-t3:.3f}s', flush=True)
+    del inputs, img, X
 inputs = Input(infile)
-t0 = time.time()
-inputs.run(1e6, seed=7)
-t1 = time.time()
-img = inputs.produce_image({'quantity': 'radiance', 'dims': '512,512'})
-t2 = time.time()
-rows = sum(len(o.X) for o in inputs._catalogue)
-print(f'Input.run(1e6): {t1-t0:.1f}s in {len(inputs._catalogue)} chunks, {rows:.3e} stored rows; '
-      f'produce_image {t2-t1:.1f}s', flush=True)
+prof = cProfile.Profile()
+prof.enable()
+with contextlib.redirect_stdout(io.StringIO()):
+    inputs.run(1e6, seed=7, context=ctx)
+prof.disable()
+pstats.Stats(prof).sort_stats('cumulative').print_stats(18)
