@@ -7,13 +7,14 @@ outeredge 25 R, uniform/flat(2.5 +- 2 km/s)/isotropic source, 1e7 packets PER GP
 record binned into a 512 x 512 radiance image (width 8 x 8 R).  One "step" = one full pass: clear
 the image, integrate all resident packets to the end with the fused persistent kernel, and (N > 1)
 sum the per-GPU image pairs over RCCL.  Inputs (X0, tables) are resident in HBM before the timed
-region; ``ms_per_step_incl_h2d`` is the same pass preceded by the upload of X0 from host memory
-and the on-device queue ordering, reported next to it.
+region; ``value_incl_h2d`` / ``ms_per_step_incl_h2d`` is the same pass with X0 coming from host
+memory through the streamed upload ("incl. H2D of X0"), reported next to it.
 
 metric = particle*steps/s, whole job: sum over ranks of rk5 steps actually taken (active packets
 only, Output.py:385) / max-over-ranks wall time.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --with-comm                # N = 1, but through every N > 1 branch (RCCL world of one)
     python bench.py --mode variable            # the adaptive-step driver (Output.py:221-366)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -26,6 +27,10 @@ environment is read; rendezvous of the RCCL unique id goes over the package's TC
 and barrier / max / sum of scalars as well as the image reduce are RCCL calls made from
 libnexoclom_hip.so on the handle's stream.  If the communicator cannot be created the bench
 prints ``"value": null`` with the reason and exits non-zero: nothing else is timed in its place.
+
+``run_rank`` is everything one rank does; tests/test_bench_ranks.py runs it on two CPU processes
+with the C oracle standing in for the device, so that no line of the N > 1 path meets hardware
+unexecuted.
 """
 import argparse
 import contextlib
@@ -44,9 +49,10 @@ if ROOT not in sys.path:
 ALGO_BYTES_PER_PARTICLE_STEP = 128      # 8 fp64 read + 8 fp64 written
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SEED = 1234
+INFILE = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=10)
@@ -56,11 +62,16 @@ def parse():
     p.add_argument('--dims', type=int, default=512)
     p.add_argument('--quantity', default='radiance')
     p.add_argument('--mode', choices=('constant', 'variable'), default='constant')
+    p.add_argument('--with-comm', action='store_true',
+                   help='create the RCCL communicator even for one rank and take every N > 1 '
+                        'branch (image all-reduce inside each timed pass, RCCL barrier / max / '
+                        'sum); the plain pass is timed beside it')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-extras', action='store_true',
-                   help='skip the untimed side measurements (other quantity, variable step)')
+                   help='skip the untimed side measurements (other quantity, variable step, '
+                        'stream-copy ceiling, clock)')
     p.add_argument('--cpu-packets', type=int, default=150_000)
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def quiet():
@@ -115,30 +126,48 @@ def cpu_baseline(args, inputs, variable=False):
                              f'in {t_c:.1f} s'}
 
 
-def profile_ceilings(k_ms):
-    """HBM traffic and the two ceilings that bind the fused kernel, from the committed PMC
-    profile (profiles/traffic.json): fp64 VALU issue (one wave64 fp64 instruction per 4 cycles
-    per SIMD) and the memory-side scattered-atomic request rate (tools/ubench_atomics.hip)."""
+def profile_ceilings(k_ms, particle_steps, clock_mhz):
+    """HBM traffic and the ceilings that bind the fused kernel.
+
+    From the committed PMC profile (profiles/traffic.json): HBM bytes, VALU wave-instructions and
+    memory-side atomic requests per launch, scaled to this run's particle*steps, and the share of
+    the kernel's cycles in which a VALU instruction was issuing (``valu_busy_frac_pmc``:
+    SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles, which charges a 32-bit instruction a full slot).
+    ``valu_issue_floor_ms`` is the cost model of DESIGN.md section 3 instead -- per wave trip
+    608 fp64 instructions at one 4-cycle issue slot, 13 v_rcp/v_rsq_f64 at 3.3 slots, 291 32-bit
+    instructions at half a slot (profiles/cost_model.json) -- at the clock THIS run held
+    (``clock_mhz``: in-kernel stamps of a diagnostic launch, or the profile's if not measured)."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if not os.path.exists(tfile):
-        return None, None
+    cfile = os.path.join(ROOT, 'profiles', 'cost_model.json')
     try:
         prof = json.load(open(tfile))
+        model = json.load(open(cfile))
     except (OSError, ValueError):
         return None, None
+    scale = particle_steps/float(prof.get('particle_steps_per_launch', particle_steps))
     traffic = prof.get('k_const_fused_bytes_per_launch')
     insts = prof.get('k_const_fused_valu_wave_insts_per_launch')
     atoms = prof.get('k_const_fused_atomic_requests_per_launch')
-    secondary = None
-    if insts and atoms:
-        valu_floor_ms = insts/(256*4*2.4e9/4)*1e3
-        atomic_floor_ms = atoms/2.4e10*1e3
-        secondary = {'valu_wave_insts_per_launch': insts, 'valu_issue_floor_ms': valu_floor_ms,
-                     'valu_issue_frac': valu_floor_ms/k_ms,
-                     'atomic_requests_per_launch': atoms, 'atomic_floor_ms': atomic_floor_ms,
-                     'atomic_frac': atomic_floor_ms/k_ms,
-                     'source': 'profiles/' + str(prof.get('tag', '')) + '_pmc.json'}
-    return traffic, secondary
+    if not (insts and atoms):
+        return traffic, None
+    mix = model['per_wave_trip']
+    slots = (mix['fp64'] + mix['transcendental']*model['slot_cost']['transcendental']
+             + mix['valu32']*model['slot_cost']['valu32'])
+    per_inst = slots/(mix['fp64'] + mix['transcendental'] + mix['valu32'])
+    clock = (clock_mhz or model['profile_clock_mhz'])*1e6
+    n_simd = 256*4
+    valu_floor_ms = insts*scale*per_inst*4/(n_simd*clock)*1e3
+    atomic_floor_ms = atoms*scale/model['atomic_requests_per_s']*1e3
+    secondary = {'valu_wave_insts_per_launch': insts*scale,
+                 'issue_slots_per_instruction': per_inst, 'clock_mhz': clock/1e6,
+                 'clock_source': 'in-kernel stamps, this run' if clock_mhz else 'profile',
+                 'valu_issue_floor_ms': valu_floor_ms, 'valu_issue_frac': valu_floor_ms/k_ms,
+                 'valu_busy_frac_pmc': prof.get('k_const_fused_valu_busy_frac'),
+                 'atomic_requests_per_launch': atoms*scale, 'atomic_floor_ms': atomic_floor_ms,
+                 'atomic_frac': atomic_floor_ms/k_ms,
+                 'source': 'profiles/' + str(prof.get('tag', '')) + '_pmc.json, '
+                           'profiles/cost_model.json'}
+    return (traffic*scale if traffic else None), secondary
 
 
 def variable_leg(ctx, inputs_var, n, passes=3):
@@ -160,13 +189,13 @@ def variable_leg(ctx, inputs_var, n, passes=3):
             call.append(dt*1e3)
     ctr = ctx.counters()
     k_ms = float(np.mean(ms))
+    ach = ALGO_BYTES_PER_PARTICLE_STEP*ctr['particle_steps']/(k_ms*1e-3)/1e9
     return {'packets': n, 'rk5_attempts': ctr['particle_steps'], 'kernel': 'k_var',
             'kernel_ms': k_ms, 'call_ms_incl_d2h': float(np.mean(call)),
             'value': ctr['particle_steps']/(k_ms*1e-3), 'unit': 'rk5 attempts/s',
             'unfinished': ctr['unfinished'],
-            'roofline': {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS,
-                         'achieved': ALGO_BYTES_PER_PARTICLE_STEP*ctr['particle_steps']/(k_ms*1e-3)/1e9,
-                         'frac': ALGO_BYTES_PER_PARTICLE_STEP*ctr['particle_steps']/(k_ms*1e-3)/1e9/HBM_PEAK_GBS}}
+            'roofline': {'bound': 'valu', 'contract_bound': 'hbm', 'unit': 'GB/s',
+                         'peak': HBM_PEAK_GBS, 'achieved': ach, 'frac': ach/HBM_PEAK_GBS}}
 
 
 def fail_line(args, world, reason):
@@ -176,40 +205,41 @@ def fail_line(args, world, reason):
             'data': 'synthetic', 'error': reason}
 
 
-def main():
-    args = parse()
+def run_rank(args, cp, make_context, emit=print):
+    """Everything one rank of the bench does.  ``cp``: the control plane (rank, world,
+    allgather_bytes, init_rccl, close); ``make_context()``: this rank's device context (raises
+    hip_api.HipError when there is none).  Rank 0 hands the JSON line to ``emit``.  Returns the
+    process exit code."""
     from nexoclom_amd import Input, Output, ModelImage, hip_api
-    from nexoclom_amd.distributed import ControlPlane, chunk_plan, pick_device
+    from nexoclom_amd.distributed import chunk_plan
     from nexoclom_amd.Output import n_output_steps
-    world = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
-    cp = ControlPlane(world)
-    rank = cp.rank
+    world, rank = cp.world, cp.rank
     variable = args.mode == 'variable'
     packets = args.packets or 10_000_000
+    comm = world > 1 or args.with_comm
 
-    infile = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
-    inputs = Input(infile)
-    inputs_var = Input(infile)
+    inputs = Input(INFILE)
+    inputs_var = Input(INFILE)
     inputs_var.options.step_size = 0.
     inputs_var.options.resolution = 1e-4
     opt = inputs.options
     nsteps, n_iter = n_output_steps(opt.endtime.value, opt.step_size)
 
-    if hip_api.device_count() < 1:
-        raise SystemExit('bench.py needs a HIP device; there is no CPU fallback')
     # every rank needs a device of its own; the ranks agree on that before anything is set up
     ctx, err = None, ''
     try:
-        ctx = hip_api.Context(pick_device(cp))
+        ctx = make_context()
     except hip_api.HipError as exc:
         err = str(exc)
     problems = [p.decode() for p in cp.allgather_bytes(err.encode())]
     if any(problems):
         if rank == 0:
-            print(json.dumps(fail_line(args, world, '; '.join(p for p in problems if p))))
+            emit(json.dumps(fail_line(args, world, '; '.join(p for p in problems if p))))
         sys.stderr.write(f'[bench rank {rank}] {err or "another rank has no device"}\n')
+        if ctx is not None:
+            ctx.close()
         cp.close()
-        sys.exit(1)
+        return 1
 
     # ---- set-up (untimed): this rank's shard = chunk `rank` of the global chunk grid ----------
     (k, c0, clen, a, b), = chunk_plan(packets*world, packets, rank*packets, (rank + 1)*packets)
@@ -229,49 +259,52 @@ def main():
     del out
 
     reduce_mode = 'none'
-    if world > 1:
+    if comm:
         try:
             cp.init_rccl(ctx)
-        except hip_api.HipError as err:
+        except hip_api.HipError as exc:
             if rank == 0:
-                print(json.dumps(fail_line(args, world, str(err))))
-            sys.stderr.write(f'[bench rank {rank}] {err}\n')
+                emit(json.dumps(fail_line(args, world, str(exc))))
+            sys.stderr.write(f'[bench rank {rank}] {exc}\n')
             cp.close()
             ctx.close()
-            sys.exit(1)
+            return 1
         reduce_mode = 'rccl-allreduce'
 
-    def job_barrier():
-        if world > 1:
+    def job_barrier(on):
+        if on:
             ctx.barrier()           # RCCL all-reduce of one double on the handle's stream
 
-    def one_step():
+    def one_step(on):
         if variable:
             ctx.integrate_var(float(run_inputs.options.resolution), opt.outeredge)
             return
         ctx.image_clear()
         ctx.integrate_const_async(opt.step_size, n_iter, opt.outeredge, image=True)
-        if world > 1:
+        if on:
             ctx.image_allreduce()
 
-    for _ in range(args.warmup):
-        one_step()
+    def timed(on, steps):
+        """K passes bracketed by barrier + synchronize on both sides."""
+        kernel_ms = []
+        job_barrier(on)
         ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(on)
+            ctx.synchronize()
+            kernel_ms.append(ctx.last_kernel_ms())     # HIP events on the handle's stream
+        ctx.synchronize()
+        job_barrier(on)
+        return time.perf_counter() - t0, kernel_ms
 
-    kernel_ms = []
-    job_barrier()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    for _ in range(args.warmup):
+        one_step(comm)
         ctx.synchronize()
-        kernel_ms.append(ctx.last_kernel_ms())     # HIP events on the handle's stream
-    ctx.synchronize()
-    job_barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, kernel_ms = timed(comm, args.steps)
 
     ctr = ctx.counters()
-    if world > 1:
+    if comm:
         elapsed = ctx.allreduce_max(elapsed)
         work_all = ctx.allreduce_sum(float(ctr['particle_steps']))
         samples_all = ctx.allreduce_sum(float(ctr['samples']))
@@ -280,27 +313,37 @@ def main():
     sec_per_step = elapsed/args.steps
     value = work_all/sec_per_step
 
-    # ---- the same pass with X0 coming from host memory (untimed for the headline) ------------
+    # --with-comm on one rank: the plain pass beside it, so the line shows what the collectives cost
+    plain = None
+    if comm and world == 1:
+        plain_s, _ = timed(False, args.steps)
+        plain = plain_s/args.steps
+
+    # ---- the same pass with X0 coming from host memory (never the headline) ---
     incl = []
     for _ in range(2):
-        job_barrier()
+        job_barrier(comm)
         ctx.synchronize()
         t0 = time.perf_counter()
         ctx.upload_soa(x0)                  # H2D of 64 B/packet + on-device queue ordering
         ctx.set_first_index(a)
-        one_step()
+        one_step(comm)
         ctx.synchronize()
-        job_barrier()
+        job_barrier(comm)
         incl.append(time.perf_counter() - t0)
     incl_s = min(incl)
-    if world > 1:
+    if comm:
         incl_s = ctx.allreduce_max(incl_s)
     del x0
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         achieved = ALGO_BYTES_PER_PARTICLE_STEP*ctr['particle_steps']/(k_ms*1e-3)/1e9
-        traffic, secondary = (None, None) if variable else profile_ceilings(k_ms)
+        extras = world == 1 and not args.no_extras
+        clock_mhz = ctx.shader_clock_mhz() if extras and hasattr(ctx, 'shader_clock_mhz') else None
+        copy_gbs = ctx.stream_copy_gbs() if extras and hasattr(ctx, 'stream_copy_gbs') else None
+        traffic, secondary = (None, None) if variable else \
+            profile_ceilings(k_ms, ctr['particle_steps'], clock_mhz)
         unit = 'rk5 attempts/s' if variable else 'particle*steps/s'
         if variable:
             workload = (f'Na at Mercury (taa 1.3), gravity+radpres+photoionisation, {packets} '
@@ -320,24 +363,35 @@ def main():
             'config': {'workload': workload, 'mode': args.mode, 'packets_per_gpu': packets,
                        'n_iter': n_iter, 'nsteps': nsteps, 'image': f'{args.dims}x{args.dims}',
                        'parallelism': f'packet-shard x{world}', 'image_reduce': reduce_mode,
-                       'control_plane': 'tcp+rccl' if world > 1 else 'none'},
+                       'control_plane': 'tcp+rccl' if comm else 'none'},
             'particle_steps_per_pass': work_all, 'samples_per_pass': samples_all,
-            'ms_per_step_incl_h2d': incl_s*1e3,
-            'value_incl_h2d': work_all/incl_s,
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': kernel, 'kernel_ms': k_ms,
+            # the pass including the host-to-device copy of X0
+            'value_incl_h2d': work_all/incl_s, 'ms_per_step_incl_h2d': incl_s*1e3,
+            'roofline': {'bound': 'valu', 'contract_bound': 'hbm',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'peak_measured': copy_gbs,
+                         'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
+                         'frac_of_measured_peak': achieved/copy_gbs if copy_gbs else None,
+                         'traffic': traffic, 'kernel': kernel, 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_particle_step': ALGO_BYTES_PER_PARTICLE_STEP,
                          'binding': 'fp64 VALU issue', 'binding_ceilings': secondary,
-                         'note': 'persistent kernel keeps packet state in registers: real HBM '
-                                 'traffic is far below the algorithmic figure; the binding '
-                                 'resource is fp64 VALU issue (see DESIGN.md)'},
+                         'note': 'achieved/peak/frac are the HBM contract of SURVEY.md 8(d) '
+                                 '(128 algorithmic bytes per particle*step against 8 TB/s; '
+                                 'peak_measured = this box\'s streaming-copy rate).  The '
+                                 'persistent kernel keeps the packet state in registers, so its '
+                                 'real HBM traffic is far below the algorithmic figure and what '
+                                 'binds it is fp64 VALU issue (bound; see DESIGN.md section 3)'},
             'device': ctx.device_name(),
         }
+        if plain is not None:
+            line['with_comm'] = {'ms_per_step_with_collectives': sec_per_step*1e3,
+                                 'ms_per_step_plain': plain*1e3,
+                                 'delta_ms_per_step': (sec_per_step - plain)*1e3,
+                                 'note': 'RCCL communicator of one rank: image all-reduce in every '
+                                         'timed pass, barrier / max / sum over RCCL'}
         if not variable:
             line['los_pixels_per_s'] = args.dims*args.dims*world/sec_per_step
             line['samples_per_s'] = samples_all/sec_per_step
-        if world == 1 and not variable and not args.no_extras:
+        if extras and not variable:
             # the same pass with the other image quantity (configs[2] words it as a "column"
             # image; the headline above uses the costlier radiance weighting), for reference
             other = 'column' if args.quantity != 'column' else 'radiance'
@@ -355,8 +409,7 @@ def main():
                                       'value': ctr['particle_steps']/(float(np.mean(ms2))*1e-3),
                                       'unit': 'particle*steps/s'}
             # the adaptive-step driver (a-4), for the record: at the reference's chunk of 1e6
-            # packets (Input.py:218; five packets per lane -- the kernel then lasts as long as its
-            # longest packet's chain of attempts, profiles/r02_var_schedule.json) and at 1e7
+            # packets (Input.py:218) and at 1e7, which is what Input.run launches at once
             line['variable_step'] = variable_leg(ctx, inputs_var, 1_000_000)
             line['variable_step_1e7'] = variable_leg(ctx, inputs_var, 10_000_000, passes=2)
         if world == 1 and not args.no_cpu_baseline:
@@ -365,11 +418,23 @@ def main():
                                                     variable)
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line))
-    if world > 1:
+        emit(json.dumps(line))
+    if comm:
         ctx.comm_destroy()
     ctx.close()
     cp.close()
+    return 0
+
+
+def main():
+    args = parse()
+    from nexoclom_amd import hip_api
+    from nexoclom_amd.distributed import ControlPlane, pick_device
+    world = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
+    cp = ControlPlane(world)
+    if hip_api.device_count() < 1:
+        raise SystemExit('bench.py needs a HIP device; there is no CPU fallback')
+    sys.exit(run_rank(args, cp, lambda: hip_api.Context(pick_device(cp))))
 
 
 if __name__ == '__main__':

@@ -385,6 +385,13 @@ int nxc_allreduce_max_f64(nxc_handle *h, double *value);   /* control plane: max
 int nxc_allreduce_sum_f64(nxc_handle *h, double *value);   /* control plane: whole-job work counters */
 int nxc_barrier(nxc_handle *h);
 
+/* ---- measurement helpers for bench.py's roofline object -------------------------------------------
+ * nxc_stream_copy_gbs: best of `reps` device-to-device streaming copies of `bytes` (16 B per lane),
+ * GB/s of bytes read + written: the box's own HBM ceiling.  nxc_shader_clock_mhz: the clock the
+ * chip holds under an fp64 load, from in-kernel stamps of a diagnostic launch. */
+int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs);
+int nxc_shader_clock_mhz(nxc_handle *h, double *mhz);
+
 /* ---- diagnostics used by the parity tests -------------------------------------------------------
  * which: 0 = exp, 1 = log, 2 = cube (r^3), 3 = sqrt, 4 = x/y with y = in2 (in2 nullable otherwise) */
 int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const double *in2,

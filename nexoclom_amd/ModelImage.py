@@ -274,8 +274,16 @@ class ModelImage(ModelResult):
         src = bounce = bodies = None
         plan = list(chunk_plan(total, chunk, lo, hi))
 
-        def host_chunk(k, clen):
-            # the whole chunk is drawn (the generator is sequential), rows [a, b) are kept
+        from .source_distribution import WindowGenerator
+        windowed = seed is not None and WindowGenerator.windowable(inputs)
+
+        def host_chunk(k, clen, lo_row, hi_row):
+            # a rank that owns only rows [lo_row, hi_row) of the chunk draws only those (the
+            # seeded stream is jumped into with PCG64.advance: bit-identical to slicing the whole
+            # draw); sources whose draws cannot be windowed draw the chunk and slice
+            if windowed and (lo_row, hi_row) != (0, clen):
+                return Output(inputs, clen, seed=seed + k, window=(clen, lo_row, hi_row),
+                              integrate=False, save=False, context=ctx)
             return Output(inputs, clen, seed=None if seed is None else seed + k,
                           integrate=False, save=False, context=ctx)
 
@@ -299,10 +307,12 @@ class ModelImage(ModelResult):
                     if pool is not None:
                         for later in plan[position:position + HOST_SAMPLER_THREADS]:
                             if later[0] not in ahead:
-                                ahead[later[0]] = pool.submit(host_chunk, later[0], later[2])
+                                ahead[later[0]] = pool.submit(host_chunk, later[0], later[2],
+                                                              later[3] - later[1],
+                                                              later[4] - later[1])
                         out = ahead.pop(k).result()
                     else:
-                        out = host_chunk(k, clen)
+                        out = host_chunk(k, clen, a - c0, b - c0)
                     bounce, bodies = out._bounce, out._bodies
                 if first:
                     ctx.set_forces(**out.forces_kwargs())
@@ -310,7 +320,8 @@ class ModelImage(ModelResult):
                     first = False
                 if sampler != 'device':
                     soa = out.x0_soa()
-                    ctx.upload_soa(soa if n == clen else np.ascontiguousarray(soa[:, a-c0:b-c0]))
+                    ctx.upload_soa(soa if soa.shape[1] == n
+                                   else np.ascontiguousarray(soa[:, a-c0:b-c0]))
                 ctx.set_bounce(bounce)
                 ctx.set_bodies(bodies)
                 ctx.set_first_index(a)

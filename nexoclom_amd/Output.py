@@ -17,8 +17,9 @@ loss_info, randgen, compress, inputs, planet) and the same column order of ``X``
   used by the fused integrate+image path), ``context`` (share one hip_api.Context),
   ``sampler`` ('numpy': the reference's seeded draw order on the host; 'device': Philox on the
   GPU, statistically equivalent, for runs where host sampling would dominate),
-  ``first_index`` (offset of this chunk in the device sampler's counter space) and
-  ``materialize_x0`` (False: leave the device-sampled states on the GPU).
+  ``first_index`` (offset of this chunk in the device sampler's counter space),
+  ``materialize_x0`` (False: leave the device-sampled states on the GPU) and ``window``
+  ((n, a, b): only rows [a, b) of the n packets the seed would draw, bit-identical to slicing).
 * the trajectory rows of a constant-step run stay in HBM (hip_api.RowStore) in exactly the form
   save() would store them -- frac > 0 rows, float32 / int32 -- and ``X`` is built from them on
   first access; ModelImage and LOSResult read the resident rows directly.  ``Output.integrate_batch``
@@ -61,7 +62,8 @@ class Output:
 
     def __init__(self, inputs, npackets, compress=True, run_model=True, seed=None, *,
                  device=0, integrate=True, keep_trajectory=True, context=None, save=True,
-                 sampler='numpy', first_index=0, materialize_x0=True, presampled=False):
+                 sampler='numpy', first_index=0, materialize_x0=True, presampled=False,
+                 window=None):
         self.inputs = inputs
         self.planet = inputs.geometry.planet
         # a finished reference Output always went through save() (Output.py:202): its frames are
@@ -72,7 +74,14 @@ class Output:
         self.filename = None
         self.idnum = None
         if run_model:
-            self.randgen = np.random.default_rng(seed=seed)
+            if window is None:
+                self.randgen = np.random.default_rng(seed=seed)
+            else:
+                # rows [a, b) of the npackets = window[0] packets the seed would draw: only those
+                # are drawn (multi-GPU shards, ModelImage._stream); everything below sees b - a
+                from .source_distribution import WindowGenerator
+                self.randgen = WindowGenerator(seed, *window)
+                npackets = window[2] - window[1]
             # the parser calls it 'geometry with starttime' (input_classes.py:75), which slips past
             # the reference's assert and dies on the missing .taa; both spellings stop here
             assert self.inputs.geometry.type not in ('geometry with time',

@@ -1876,6 +1876,70 @@ int nxc_barrier(nxc_handle *h)
     return nxc_allreduce_max_f64(h, &v);
 }
 
+int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs)
+{
+    return guarded([&]() -> int {
+    if (!h || !gbs || bytes < (1 << 20) || reps < 1) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n16 = bytes / 16;
+    char *buf = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&buf), (size_t)n16 * 32));
+    hipError_t e = hipMemsetAsync(buf, 1, (size_t)n16 * 32, h->stream);
+    float best = 0.f;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    for (int r = 0; r <= reps && e == hipSuccess; r++) {         // first round warms up
+        e = hipEventRecord(a, h->stream);
+        hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)(h->n_cu * 16)), dim3(NXC_BLOCK), 0, h->stream,
+                           reinterpret_cast<const nxc_v2d *>(buf),
+                           reinterpret_cast<nxc_v2d *>(buf + (size_t)n16 * 16), n16);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(b, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+        if (r > 0 && e == hipSuccess && (best == 0.f || ms < best)) best = ms;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("stream copy: ") + hipGetErrorString(e));
+    *gbs = 2.0 * (double)n16 * 16.0 / ((double)best * 1e-3) / 1e9;      // bytes read + written
+    return NXC_OK;
+    });
+}
+
+int nxc_shader_clock_mhz(nxc_handle *h, double *mhz)
+{
+    return guarded([&]() -> int {
+    if (!h || !mhz) return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int blocks = h->n_cu, waves = blocks * (BLOCK_PERSIST / 64);
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap,
+                    (size_t)waves * 3 * sizeof(unsigned long long));
+    if (rc) return rc;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(h->d_scratch);
+    std::vector<unsigned long long> got((size_t)waves * 3);
+    for (int round = 0; round < 2; round++) {                    // the first brings the clock up
+        hipLaunchKernelGGL(k_clock, dim3(blocks), dim3(BLOCK_PERSIST), 0, h->stream, d,
+                           round ? 40000 : 400000, 1.0);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(got.data(), d, got.size() * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> f;
+    for (int w = 0; w < waves; w++)
+        if (got[3 * (size_t)w + 1] > 0)
+            f.push_back((double)got[3 * (size_t)w] / (double)got[3 * (size_t)w + 1] * 100.0);
+    if (f.empty()) return fail(NXC_ERR_HIP, "no clock stamps came back");
+    std::nth_element(f.begin(), f.begin() + f.size() / 2, f.end());
+    *mhz = f[f.size() / 2];
+    return NXC_OK;
+    });
+}
+
 int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const double *in2,
                    double *out)
 {

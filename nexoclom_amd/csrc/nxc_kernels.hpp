@@ -640,12 +640,41 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
 
-// save()'s 32-bit down-cast (Output.py:528-543) for rows that are about to leave the device
-__global__ void k_narrow_f32(const double *__restrict__ in, float *__restrict__ out, int64_t n)
+// ---- measurement helpers (bench.py's roofline object) --------------------------------------------
+// Streaming copy, 16 bytes per lane: the box's own HBM ceiling next to the 8 TB/s of the data sheet.
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_stream_copy(const nxc_v2d *__restrict__ src, nxc_v2d *__restrict__ dst, int64_t n16)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
          i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (float)in[i];
+        dst[i] = src[i];
+}
+
+// Shader clock under fp64 load: every wave runs `iters` rounds of eight independent fp64 fma
+// chains between two pairs of stamps; clock = d(s_memtime) / d(s_memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, DVFS item 6).  Diagnostic launch of its own: no product kernel carries stamps.
+__global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
+k_clock(unsigned long long *__restrict__ out, int iters, double seed)
+{
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j] = seed + threadIdx.x + j;
+    const double m = 0.999999, c = 1e-9;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = __builtin_fma(a[j], m, c);
+    }
+    double sink = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sink += a[j];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        out[3 * w] = t1 - t0;
+        out[3 * w + 1] = r1 - r0;
+        out[3 * w + 2] = (unsigned long long)__double_as_longlong(sink);   // keeps the chains alive
+    }
 }
 
 __global__ void k_math(const unsigned char *__restrict__ blob, int which, int64_t n,

@@ -30,7 +30,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_set_bounce', 'nxc_set_first_index', 'nxc_set_bodies',
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
-           'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info')
+           'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info',
+           'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz')
 ABI_VERSION = 2
 
 
@@ -595,6 +596,20 @@ class Context:
 
     def barrier(self):
         self._check(self.lib.nxc_barrier(self._h))
+
+    # -- measurement helpers ----------------------------------------------------------------
+    def stream_copy_gbs(self, nbytes=1 << 31, reps=5):
+        """The box's streaming-copy rate, GB/s of bytes read + written."""
+        gbs = C.c_double(0)
+        self._check(self.lib.nxc_stream_copy_gbs(self._h, C.c_int64(nbytes), C.c_int(reps),
+                                                 C.byref(gbs)))
+        return float(gbs.value)
+
+    def shader_clock_mhz(self):
+        """The shader clock the chip holds under an fp64 load (in-kernel stamps)."""
+        mhz = C.c_double(0)
+        self._check(self.lib.nxc_shader_clock_mhz(self._h, C.byref(mhz)))
+        return float(mhz.value)
 
     # -- diagnostics ------------------------------------------------------------------------
     def math(self, which, x, y=None):

@@ -27,6 +27,44 @@ from .input_classes import InputError
 TWO_PI = 2*np.pi
 
 
+# ---- a window of the seeded stream ---------------------------------------------------------------
+class WindowGenerator:
+    """Rows [a, b) of every ``n``-long uniform draw of ``numpy.random.default_rng(seed)``.
+
+    The reference draws whole vectors, ``randgen.random(npackets)``, one after the other
+    (Output.py:138-139; source_distribution.py:51-62,169-171,202-212), and each double consumes
+    exactly one 64-bit output of the PCG64 stream: element i of draw j sits at stream position
+    j*n + i.  A rank that owns only rows [a, b) of a chunk of n packets therefore jumps there with
+    ``PCG64.advance`` (O(log) 128-bit multiplications) instead of drawing -- and discarding -- the
+    whole chunk on every rank that overlaps it.  Bit-identical to slicing the full draw
+    (tests/test_host.py).  Only ``random`` can be windowed: ``standard_normal`` (ziggurat) uses a
+    data-dependent number of outputs, so gaussian sources draw whole chunks (``windowable``)."""
+
+    def __init__(self, seed, n, a, b):
+        if seed is None or not 0 <= a <= b <= n:
+            raise ValueError('a window needs a seed and 0 <= a <= b <= n')
+        self.n, self.a, self.b = int(n), int(a), int(b)
+        self._start = np.random.PCG64(seed).state      # = default_rng(seed).bit_generator.state
+        self._draws = 0
+
+    def random(self, size):
+        assert size == self.b - self.a, 'a windowed generator draws windows of whole vectors'
+        engine = np.random.PCG64(0)
+        engine.state = self._start
+        engine.advance(self._draws*self.n + self.a)
+        self._draws += 1
+        return np.random.Generator(engine).random(size)
+
+    def standard_normal(self, size):
+        raise TypeError('standard_normal cannot be windowed (see WindowGenerator.windowable)')
+
+    @staticmethod
+    def windowable(inputs):
+        """Whether every seeded draw these inputs make is a ``random(npackets)`` vector."""
+        gaussian = inputs.speeddist.type.lower() == 'gaussian' and inputs.speeddist.sigma != 0.
+        return not gaussian
+
+
 # ---- geometry helpers ---------------------------------------------------------------------------
 def xyz_from_lonlat(lon, lat, isplan, exobase):
     """Surface point of longitude/latitude on the sphere r = exobase, as a (3, n) array

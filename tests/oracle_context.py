@@ -13,7 +13,12 @@ from oracle.c_oracle import COracle
 
 
 class OracleContext:
-    def __init__(self, threads=2):
+    def __init__(self, threads=2, cp=None, seat='oracle:0'):
+        """cp + seat: only for code that also drives the communicator (bench.run_rank): the
+        collectives of the stand-in go over that control plane, ``seat`` plays the PCI bus id."""
+        self.cp, self.seat = cp, seat
+        self.log = []                      # communicator / collective calls, in order
+        self._last_ms = 0.0
         self.co = COracle()
         self.threads = threads
         self.n_packets = 0
@@ -75,9 +80,57 @@ class OracleContext:
     def counters(self):
         return dict(self._ctr)
 
+    # -- what bench.run_rank needs beyond sharded_image ----------------------------------------
+    def device_name(self):
+        return 'C oracle (test stand-in for a device)'
+
+    def bus_id(self):
+        return self.seat
+
+    def synchronize(self):
+        pass
+
+    def close(self):
+        self.log.append('close')
+
+    def last_kernel_ms(self):
+        return self._last_ms
+
+    def integrate_const_async(self, step, n_iter, outeredge, image=True):
+        self.integrate_const(step, n_iter, outeredge, image=image)
+
+    def comm_unique_id(self):
+        self.log.append('comm_unique_id')
+        return bytes(range(128))
+
+    def comm_init(self, unique_id, rank, nranks):
+        assert unique_id == bytes(range(128)) and (rank, nranks) == (self.cp.rank, self.cp.world)
+        self.log.append('comm_init')
+
+    def comm_destroy(self):
+        self.log.append('comm_destroy')
+
+    def image_allreduce(self):
+        self.log.append('image_allreduce')
+        self._image, self._counts = self.cp.allreduce_images_host(self._image, self._counts)
+
+    def allreduce_max(self, value):
+        self.log.append('allreduce_max')
+        return self.cp.reduce(value, 'MAX')
+
+    def allreduce_sum(self, value):
+        self.log.append('allreduce_sum')
+        return self.cp.reduce(value, 'SUM')
+
+    def barrier(self):
+        self.log.append('barrier')
+        self.cp.barrier()
+
     def integrate_const(self, step, n_iter, outeredge, image=False, nrec=0, want_final=False,
                         want_steps=False):
         assert nrec == 0
+        import time
+        t0 = time.perf_counter()
         X0 = np.ascontiguousarray(self._soa.T)
         res = self.co.integrate_const(self._forces, X0, step, n_iter, outeredge,
                                       img=self._desc if image else None, threads=self.threads)
@@ -87,5 +140,6 @@ class OracleContext:
         self._ctr = dict(particle_steps=res['work'], samples=0,
                          samples_binned=int(res['counts'].sum()) if image else 0, nonfinite=0,
                          bad_step=0, neg_frac=0, unfinished=0)
+        self._last_ms = (time.perf_counter() - t0)*1e3
         self.calls.append((self.n_packets, self._first))
         return dict(traj=None, final=res['final'], steps=res['steps'])

@@ -45,11 +45,23 @@ def _worker(rank, world, port, tmpdir, kind):
     assert cp.allgather_bytes(b'r%d' % rank) == [b'r%d' % r for r in range(world)]
 
     inputs = Input(INPUT)
+    # a rank draws only the rows it owns of a chunk it shares (WindowGenerator): record the sizes
+    from nexoclom_amd.source_distribution import WindowGenerator
+    windows, draw = [], WindowGenerator.random
+
+    def spy(self, size):
+        windows.append(size)
+        return draw(self, size)
+    WindowGenerator.random = spy
     for sampler in ('numpy', 'device'):
         ctx = OracleContext()
         with contextlib.redirect_stdout(io.StringIO()):
             part = sharded_image(inputs, PARAMS, N, SEED, cp=cp, context=ctx, sampler=sampler,
                                  packs_per_it=CHUNK, reduce='host')
+        if sampler == 'numpy':
+            # chunk 1 (rows 500..999) is shared: rank 0 draws its 101 rows, rank 1 its 399, five
+            # vectors each (sin lat, lon, speed, sin alt, azimuth); whole chunks are not windowed
+            assert windows == [101 if rank == 0 else 399]*5, windows
         # this rank integrated only its own rows, addressed by their GLOBAL index
         want = [(500, 0), (101, 500)] if rank == 0 else [(399, 601), (201, 1000)]
         assert ctx.calls == want, (sampler, rank, ctx.calls)

@@ -256,10 +256,19 @@ def test_rccl_single_rank_allreduce(ctx, coracle):
     ctx.image_allreduce()
     ctx.barrier()
     assert ctx.allreduce_max(3.25) == 3.25
+    # the work / sample totals of bench.py go through nxc_allreduce_sum_f64: exact for every
+    # integer-valued double a counter can hold, and for a sum that is not representable in fp32
+    for v in (0.0, 1.0, 1280065134.0, 2.0**53 - 1, -7.25, 1e-300, 0.1 + 0.2):
+        assert ctx.allreduce_sum(v) == v and ctx.allreduce_max(v) == v
     image1, counts1 = ctx.image_download()
     ctx.comm_destroy()
     assert np.array_equal(image0, image1) and np.array_equal(counts0, counts1)
     assert counts0.sum() > 0
+    # after nxc_comm_destroy every collective refuses instead of hanging or falling back
+    from nexoclom_amd import hip_api
+    for call in (ctx.image_allreduce, ctx.barrier, lambda: ctx.allreduce_sum(1.0)):
+        with pytest.raises(hip_api.HipError, match='nxc_comm_init'):
+            call()
 
 
 @pytest.mark.parametrize('bounce', [False, True])

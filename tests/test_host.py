@@ -373,3 +373,46 @@ def test_output_frames_are_retyped_like_save_and_restore(tmp_path):
     assert (aplanet, vr) == (0.35, 9.7) and len(samples) == 5
     for got, c in zip(samples, Output.IMAGE_COLS):
         assert got.dtype == np.float32 and np.array_equal(got, cols['X.' + c])
+
+
+def test_windowed_host_draws_equal_slices_of_the_full_draw():
+    """A rank that owns rows [a, b) of a chunk draws only those (WindowGenerator: PCG64.advance to
+    stream position draw*n + a): every X0 column must be bit-identical to the same rows of the
+    full chunk's X0, for the constant-step sources and for the variable-step run (whose launch
+    times are one more draw in front)."""
+    import contextlib
+    import io
+    from nexoclom_amd import Input, Output
+    from nexoclom_amd.source_distribution import WindowGenerator
+    pkg = os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles')
+    for name, variable in (('Na.mercury.bench.input', False), ('Na.mercury.bench.input', True),
+                           ('Ca.isotropic.flat.input', False)):
+        inputs = Input(os.path.join(pkg, name))
+        if variable:
+            inputs.options.step_size = 0.
+            inputs.options.resolution = 1e-4
+        assert WindowGenerator.windowable(inputs)
+        n, seed = 2003, 77
+        with contextlib.redirect_stdout(io.StringIO()):
+            full = Output(inputs, n, seed=seed, integrate=False, save=False)
+            for a, b in ((0, n), (0, 1), (5, 5), (1, 700), (1999, n), (640, 1311)):
+                part = Output(inputs, n, seed=seed, window=(n, a, b), integrate=False, save=False)
+                assert part.npackets == b - a and len(part.X0) == b - a
+                assert list(part.X0.columns) == list(full.X0.columns)
+                for c in full.X0.columns:
+                    assert np.array_equal(part.X0[c].values, full.X0[c].values[a:b]), (name, c, a, b)
+                assert np.array_equal(part.x0_soa(), full.x0_soa()[:, a:b])
+    # the raw stream: five successive vectors, window by window
+    n = 1000
+    rng = np.random.default_rng(5)
+    vectors = [rng.random(n) for _ in range(5)]
+    win = WindowGenerator(5, n, 123, 877)
+    for v in vectors:
+        assert np.array_equal(win.random(754), v[123:877])
+    # gaussian speeds cannot be windowed: such inputs draw whole chunks
+    inputs = Input(os.path.join(pkg, 'Na.mercury.bench.input'))
+    inputs.speeddist.type = 'gaussian'
+    inputs.speeddist.sigma = type(inputs.speeddist.vprob)(0.5, 'km/s')
+    assert not WindowGenerator.windowable(inputs)
+    with pytest.raises(TypeError):
+        win.standard_normal(10)
