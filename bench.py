@@ -78,6 +78,21 @@ def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 points at stderr inside the block: librccl prints a version banner on
+    stdout when a communicator is created, and stdout carries exactly one JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def cpu_baseline(args, inputs, variable=False):
     """The reference's CPU path, timed beside the GPU number on the same box: the NumPy oracle's
     constant-step driver (bit-identical to the reference's rk5/state arithmetic) on a bounded
@@ -261,7 +276,8 @@ def run_rank(args, cp, make_context, emit=print):
     reduce_mode = 'none'
     if comm:
         try:
-            cp.init_rccl(ctx)
+            with stdout_to_stderr():
+                cp.init_rccl(ctx)
         except hip_api.HipError as exc:
             if rank == 0:
                 emit(json.dumps(fail_line(args, world, str(exc))))

@@ -238,6 +238,21 @@ typedef struct nxc_source_desc {
     const double *speed_v;     /* [n_speed] km/s                                                */
     int64_t map_nlon, map_nlat;   /* spatial_type 1: density map dims (>= 2 each)               */
     const double *map;     /* [map_nlon][map_nlat], >= 0                                        */
+    /* generator 1: the reference's own seeded stream, numpy.random.default_rng(seed) = PCG64
+     * (Output.py:92), reproduced on the device: the packets are rows pcg_row0 .. pcg_row0 + n - 1
+     * of the pcg_n-packet vectors the reference would draw one after the other ([launch time,]
+     * sin latitude, longitude, speed, [sin altitude, azimuth]); the uniforms are bit-identical
+     * to Generator.random(pcg_n), the states equal the host sampler's to libm rounding.  Only
+     * sources whose every draw is such a vector: spatial_type 0, speed_type 0 (flat), any
+     * angular_type.  pcg_state / pcg_inc: PCG64(seed).state['state'] as {high, low} words.      */
+    int32_t generator;     /* 0 Philox-4x32-10 (counter-based, statistical parity), 1 PCG64     */
+    int32_t reserved2;
+    uint64_t pcg_state[2], pcg_inc[2];
+    int64_t pcg_n, pcg_row0;
+    /* dest_total > 0: the n packets are piece [dest_offset, dest_offset + n) of a resident set of
+     * dest_total packets that several calls fill (pieces in ascending order, the first with
+     * dest_offset 0; the set is usable once the last piece is in).  0: they are the whole set.    */
+    int64_t dest_offset, dest_total;
 } nxc_source_desc;
 
 int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out);
@@ -391,6 +406,12 @@ int nxc_barrier(nxc_handle *h);
  * chip holds under an fp64 load, from in-kernel stamps of a diagnostic launch. */
 int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs);
 int nxc_shader_clock_mhz(nxc_handle *h, double *mhz);
+
+/* Diagnostics of generator 1: out[nvec][count] = the uniforms of draws 0..nvec-1 for rows row0 ..
+ * row0 + count - 1 of n-packet vectors, i.e. default_rng(seed).random(n)[row0:row0+count] nvec
+ * times in a row. */
+int nxc_pcg64_uniforms(nxc_handle *h, const uint64_t state[2], const uint64_t inc[2], int64_t n,
+                       int64_t row0, int64_t count, int32_t nvec, double *out);
 
 /* ---- diagnostics used by the parity tests -------------------------------------------------------
  * which: 0 = exp, 1 = log, 2 = cube (r^3), 3 = sqrt, 4 = x/y with y = in2 (in2 nullable otherwise) */

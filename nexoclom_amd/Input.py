@@ -108,7 +108,7 @@ class Input:
 
     def run(self, npackets, packs_per_it=None, overwrite=False, compress=True,
             distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None,
-            sampler='numpy', batch=True):
+            sampler='numpy', batch=True, generator='philox'):
         """Integrate until the catalogue holds ``npackets`` packets (Input.py:175-268).
 
         Every pass plans ``ceil(todo / size)`` Outputs of ``size = min(todo, chunk_size)``
@@ -117,7 +117,9 @@ class Input:
         reference's stream; the reference itself passes the same seed to every Output
         (Input.py:246), which repeats identical packets.  ``sampler='device'`` draws the initial
         states on the GPU instead (counter-based: the k-th Output continues the index space of
-        the ones before it under the one ``seed``).
+        the ones before it under the one ``seed``; with ``generator='pcg64'`` the device follows
+        the host sampler's seeded streams instead -- Output k from ``seed + k``, the same packets
+        as sampler='numpy' to libm rounding, without the host drawing or uploading them).
 
         The Outputs of a pass are independent, so they are INTEGRATED TOGETHER (``batch``): one
         upload, one launch of each kernel over all their packets (Output.integrate_batch), each
@@ -160,7 +162,11 @@ class Input:
                 for g in range(group):
                     number += 1
                     print(f'Starting iteration #{number} of {passes}')
-                    if sampler == 'device':
+                    if sampler == 'device' and generator == 'pcg64':
+                        draw = dict(seed=seed + made, sampler='device', generator='pcg64',
+                                    first_index=drawn, presampled=together,
+                                    materialize_x0=not together)
+                    elif sampler == 'device':
                         draw = dict(seed=seed, sampler='device', first_index=drawn,
                                     presampled=together, materialize_x0=not together)
                     else:
@@ -173,7 +179,15 @@ class Input:
                     drawn += size
                     made += 1
                 if together and outs:
-                    if sampler == 'device':
+                    if sampler == 'device' and generator == 'pcg64':
+                        # every Output follows its own seeded stream: one piece of the resident
+                        # set per Output
+                        src, whole = outs[0].source_desc(), size*len(outs)
+                        for g, out in enumerate(outs):
+                            out._adopt_x0(context.sample_packets(
+                                size, seed + made - len(outs) + g, outs[0]._first_index,
+                                download=True, pcg64=(size, 0), piece=(g*size, whole), **src))
+                    elif sampler == 'device':
                         lead = outs[0]
                         soa = context.sample_packets(size*len(outs), 0 if seed is None else seed,
                                                      lead._first_index, download=True,

@@ -130,7 +130,7 @@ class ModelResult:
 class ModelImage(ModelResult):
     def __init__(self, inputs, params, overwrite=False, distribute=None, *, npackets=None,
                  seed=None, packs_per_it=None, downcast=True, device=0, context=None,
-                 sampler='numpy', shard=None, finalize=True):
+                 sampler='numpy', shard=None, finalize=True, generator='philox'):
         super().__init__(inputs, params)
         self.type = 'image'
         self.origin = self.params.get('origin', inputs.geometry.planet)
@@ -151,7 +151,7 @@ class ModelImage(ModelResult):
             lo, hi = (0, total) if shard is None else (int(shard[0]), int(shard[1]))
             if not 0 <= lo <= hi <= total:
                 raise ValueError('shard must be an index range inside [0, npackets]')
-            self._stream(total, seed, packs_per_it, downcast, sampler, lo, hi)
+            self._stream(total, seed, packs_per_it, downcast, sampler, lo, hi, generator)
         else:
             self._from_catalogue()
         if finalize:
@@ -250,14 +250,18 @@ class ModelImage(ModelResult):
         return (Histogram2dResult(image, self.xedges, self.zedges),
                 Histogram2dResult(counts.astype(float), self.xedges, self.zedges))
 
-    def _stream(self, total, seed, packs_per_it, downcast, sampler='numpy', lo=0, hi=None):
+    def _stream(self, total, seed, packs_per_it, downcast, sampler='numpy', lo=0, hi=None,
+                generator='philox'):
         """Fused integrate + image over the packets [lo, hi) of a run of ``total`` packets.
 
         The run is cut into chunks like Input.run does (Input.py:243-246); the chunk grid depends
         only on ``total`` and ``packs_per_it`` (distributed.chunk_plan), and chunk k of the host
         sampler is drawn from the generator seeded ``seed + k``, so the packets with global index
         in [lo, hi) are the same packets whether this process handles the whole run or one shard
-        of it.  The device sampler is counter-based on the global index."""
+        of it.  The device sampler is counter-based on the global index
+        (generator='philox'), or follows the host sampler's own seeded streams, chunk k from
+        ``seed + k`` (generator='pcg64': the same packets as sampler='numpy' to libm rounding,
+        drawn where they are integrated)."""
         from .Output import Output, n_output_steps
         from .distributed import chunk_plan
         inputs = self.inputs
@@ -296,7 +300,18 @@ class ModelImage(ModelResult):
         try:
             for position, (k, c0, clen, a, b) in enumerate(plan):
                 n = b - a
-                if sampler == 'device' and not first:
+                if sampler == 'device' and generator == 'pcg64':
+                    if seed is None:
+                        raise ValueError("generator='pcg64' needs a seed")
+                    if first:
+                        out = Output(inputs, clen, seed=seed + k, integrate=False, save=False,
+                                     context=ctx, sampler='device', generator='pcg64',
+                                     window=(clen, a - c0, b - c0), first_index=a,
+                                     materialize_x0=False)
+                        src, bounce, bodies = out.source_desc(), out._bounce, out._bodies
+                    else:
+                        ctx.sample_packets(n, seed + k, a, pcg64=(clen, a - c0), **src)
+                elif sampler == 'device' and not first:
                     # same inputs, next slice of the counter space: no need to rebuild the tables
                     ctx.sample_packets(n, 0 if seed is None else seed, a, **src)
                 elif sampler == 'device':     # one counter space: packet i is draw block i

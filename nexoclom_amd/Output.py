@@ -18,8 +18,11 @@ loss_info, randgen, compress, inputs, planet) and the same column order of ``X``
   ``sampler`` ('numpy': the reference's seeded draw order on the host; 'device': Philox on the
   GPU, statistically equivalent, for runs where host sampling would dominate),
   ``first_index`` (offset of this chunk in the device sampler's counter space),
-  ``materialize_x0`` (False: leave the device-sampled states on the GPU) and ``window``
-  ((n, a, b): only rows [a, b) of the n packets the seed would draw, bit-identical to slicing).
+  ``materialize_x0`` (False: leave the device-sampled states on the GPU), ``window``
+  ((n, a, b): only rows [a, b) of the n packets the seed would draw, bit-identical to slicing)
+  and ``generator`` ('pcg64': the device sampler follows the seeded HOST stream -- NumPy's PCG64,
+  the uniforms bit for bit -- instead of its own Philox counters; uniform / flat / isotropic |
+  radial sources).
 * the trajectory rows of a constant-step run stay in HBM (hip_api.RowStore) in exactly the form
   save() would store them -- frac > 0 rows, float32 / int32 -- and ``X`` is built from them on
   first access; ModelImage and LOSResult read the resident rows directly.  ``Output.integrate_batch``
@@ -63,7 +66,7 @@ class Output:
     def __init__(self, inputs, npackets, compress=True, run_model=True, seed=None, *,
                  device=0, integrate=True, keep_trajectory=True, context=None, save=True,
                  sampler='numpy', first_index=0, materialize_x0=True, presampled=False,
-                 window=None):
+                 window=None, generator='philox'):
         self.inputs = inputs
         self.planet = inputs.geometry.planet
         # a finished reference Output always went through save() (Output.py:202): its frames are
@@ -80,8 +83,14 @@ class Output:
                 # rows [a, b) of the npackets = window[0] packets the seed would draw: only those
                 # are drawn (multi-GPU shards, ModelImage._stream); everything below sees b - a
                 from .source_distribution import WindowGenerator
-                self.randgen = WindowGenerator(seed, *window)
+                self.randgen = WindowGenerator(seed, *window) if sampler == 'numpy' else None
                 npackets = window[2] - window[1]
+            if generator not in ('philox', 'pcg64'):
+                raise ValueError("generator must be 'philox' or 'pcg64'")
+            if generator == 'pcg64' and (sampler != 'device' or seed is None):
+                raise ValueError("generator='pcg64' is the device sampler's reproduction of the "
+                                 "seeded host stream: it needs sampler='device' and a seed")
+            self.generator = generator
             # the parser calls it 'geometry with starttime' (input_classes.py:75), which slips past
             # the reference's assert and dies on the missing .taa; both spellings stop here
             assert self.inputs.geometry.type not in ('geometry with time',
@@ -151,7 +160,8 @@ class Output:
                 # (Input.run takes all its chunks in one go)
                 soa = None if presampled else self.context().sample_packets(
                     npackets, 0 if seed is None else seed, first_index,
-                    download=materialize_x0, **self.source_desc())
+                    download=materialize_x0, **self.stream_window(seed, window),
+                    **self.source_desc())
                 self._resident = not presampled
                 if materialize_x0 and not presampled:
                     self._adopt_x0(soa)
@@ -222,6 +232,14 @@ class Output:
         if self.radpres is not None:
             kw.update(v_tab=self.radpres.velocity, a_tab=self.radpres.accel)
         return kw
+
+    def stream_window(self, seed, window=None):
+        """``pcg64=`` argument of hip_api.Context.sample_packets for this Output: with
+        generator='pcg64' its packets are rows [a, b) of the vectors default_rng(seed) would draw
+        for ``window = (n, a, b)`` (the whole Output when there is no window); {} for Philox."""
+        if getattr(self, 'generator', 'philox') != 'pcg64':
+            return {}
+        return {'pcg64': (self.npackets, 0) if window is None else (window[0], window[1])}
 
     def source_desc(self):
         """Keyword arguments of hip_api.Context.sample_packets for these inputs: the scalar fields

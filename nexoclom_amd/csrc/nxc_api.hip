@@ -207,6 +207,38 @@ LutDesc placed_lut(LutDesc d, size_t base)
     return d;
 }
 
+// Affine maps of NumPy's PCG64 for the device sampler (nxc_kernels.hpp: PcgK): entry b <
+// NXC_PCG_BITS advances 2^b steps, entry NXC_PCG_BITS + v advances v*n steps (the start of draw
+// vector v).  state' = mult^d state + inc (mult^d - 1)/(mult - 1), accumulated by squaring like
+// pcg_advance_lcg_128 (numpy/random/src/pcg64/pcg64.c).
+typedef unsigned __int128 u128;
+const u128 PCG_MULT = ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL;
+
+void pcg_advance_map(u128 delta, u128 inc, u128 *a_out, u128 *c_out)
+{
+    u128 acc_mult = 1, acc_plus = 0, cur_mult = PCG_MULT, cur_plus = inc;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    *a_out = acc_mult;
+    *c_out = acc_plus;
+}
+
+std::vector<u128> pcg_tables(u128 inc, int64_t n)
+{
+    std::vector<u128> t((size_t)2 * (NXC_PCG_BITS + NXC_PCG_VECS));
+    for (int b = 0; b < NXC_PCG_BITS; b++) pcg_advance_map((u128)1 << b, inc, &t[2 * b], &t[2 * b + 1]);
+    for (int v = 0; v < NXC_PCG_VECS; v++)
+        pcg_advance_map((u128)v * (u128)n, inc, &t[2 * (NXC_PCG_BITS + v)], &t[2 * (NXC_PCG_BITS + v) + 1]);
+    return t;
+}
+
 // Largest double x with sqrt(x) <= e (host sqrt is correctly rounded): r2 > x <=> sqrt(r2) > e,
 // the constant driver's escape test (Output.py:395,410) without a device square root.
 double sqrt_threshold(double e)
@@ -1411,6 +1443,16 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         d->spatial_type < 0 || d->spatial_type > 1 || !(d->unit_km > 0) || !(d->exobase > 0))
         return fail(NXC_ERR_ARG, "bad nxc_source_desc");
     const bool tab_speed = d->speed_type == 2, spot = d->spatial_type == 1;
+    const bool pcg = d->generator == 1;
+    if (d->generator != 0 && d->generator != 1) return fail(NXC_ERR_ARG, "nxc_source_desc: generator must be 0 or 1");
+    if (pcg) {
+        if (d->spatial_type != 0 || d->speed_type != 0)
+            return fail(NXC_ERR_ARG, "generator 1 (PCG64) covers the sources whose every draw is a "
+                                     "random(npackets) vector: uniform surface, flat speeds");
+        if (d->pcg_n < 1 || d->pcg_row0 < 0 || d->pcg_row0 + n > d->pcg_n ||
+            d->pcg_n >= ((int64_t)1 << (NXC_PCG_BITS - 1)) || !(d->pcg_inc[1] & 1ull))
+            return fail(NXC_ERR_ARG, "nxc_source_desc: PCG64 window outside its draw vectors");
+    }
     if (tab_speed) {
         if (d->n_speed < 2 || d->n_speed > (1 << 24) || !d->speed_cdf || !d->speed_v)
             return fail(NXC_ERR_ARG, "nxc_source_desc: tabulated speeds need n_speed >= 2 and both tables");
@@ -1432,15 +1474,28 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         if (!(map_max > 0.0)) return fail(NXC_ERR_ARG, "nxc_source_desc: density map is all zero");
     }
     HIPCHK(hipSetDevice(h->device));
-    const size_t bytes = (size_t)8 * n * sizeof(double);
+    const int64_t total = d->dest_total > 0 ? d->dest_total : n;
+    const int64_t offset = d->dest_total > 0 ? d->dest_offset : 0;
+    if (offset < 0 || offset + n > total) return fail(NXC_ERR_ARG, "nxc_source_desc: piece outside its set");
+    const size_t bytes = (size_t)8 * total * sizeof(double);
+    if (offset > 0 && (h->packets_cap < bytes || h->n_packets != total))
+        return fail(NXC_ERR_STATE, "nxc_packets_sample: pieces of a set must start with dest_offset 0");
     int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, bytes);
     if (rc) return rc;
     const size_t n_sp = tab_speed ? (size_t)d->n_speed : 0;
     const size_t n_map = spot ? (size_t)(d->map_nlon * d->map_nlat) : 0;
-    if (n_sp + n_map) {
+    const size_t n_pcg = pcg ? (size_t)4 * (NXC_PCG_BITS + NXC_PCG_VECS) : 0;   // doubles' worth
+    if (n_sp + n_map + n_pcg) {
         if ((rc = ensure(reinterpret_cast<void **>(&h->d_source), &h->source_cap,
-                         (2 * n_sp + n_map) * sizeof(double))))
+                         (2 * n_sp + n_map + n_pcg) * sizeof(double))))
             return rc;
+        if (pcg) {
+            const u128 inc = ((u128)d->pcg_inc[0] << 64) | d->pcg_inc[1];
+            const std::vector<u128> maps = pcg_tables(inc, d->pcg_n);
+            HIPCHK(hipMemcpyAsync(h->d_source, maps.data(), maps.size() * sizeof(u128),
+                                  hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));      // the table is a local
+        }
         if (n_sp) {
             HIPCHK(hipMemcpyAsync(h->d_source, d->speed_cdf, n_sp * 8, hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(h->d_source + n_sp, d->speed_v, n_sp * 8, hipMemcpyHostToDevice, h->stream));
@@ -1459,22 +1514,41 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     K.map_nlon = spot ? (int)d->map_nlon : 0; K.map_nlat = spot ? (int)d->map_nlat : 0;
     K.map_max = map_max;
     K.speed_cdf = h->d_source; K.speed_v = h->d_source + n_sp; K.map = h->d_source + 2 * n_sp;
+    K.generator = d->generator;
+    if (pcg) {       // (pcg excludes the tabulated sources, so the maps sit at the buffer's start)
+        K.pcg.state = ((u128)d->pcg_state[0] << 64) | d->pcg_state[1];
+        K.pcg.row0 = d->pcg_row0;
+        K.pcg.maps = reinterpret_cast<const nxc_u128 *>(h->d_source);
+    }
+    K.stride = total;
+    K.offset = offset;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     if ((rc = begin_timed(h))) return rc;
     hipLaunchKernelGGL(k_sample, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0, h->stream, K,
                        n, h->d_packets, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
-    h->n_packets = n;
-    h->rows_total = -1;
-    h->first_id = d->first_index;
     DevCounters c;
     HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (c.unfinished)
+    if (c.unfinished) {
+        h->n_packets = 0;            // never-accepted candidates must not pass for packets
+        h->have_order = false;
         return fail(NXC_ERR_ARG, "nxc_packets_sample: " + std::to_string(c.unfinished) +
                                  " packets found no launch point in the density map (is it "
                                  "almost everywhere zero?)");
+    }
+    h->n_packets = total;
+    h->rows_total = -1;
+    if (offset == 0) h->first_id = d->first_index;
+    h->have_order = false;
+    if (soa_out)        // this piece's eight columns
+        HIPCHK(hipMemcpy2DAsync(soa_out, (size_t)n * 8, h->d_packets + offset, (size_t)total * 8,
+                                (size_t)n * 8, 8, hipMemcpyDeviceToHost, h->stream));
+    if (offset + n < total) {        // more pieces to come: the queue order waits for the last
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return NXC_OK;
+    }
     double vmax;
     if (tab_speed) {
         vmax = 0.0;
@@ -1484,8 +1558,8 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         vmax = (d->speed_type == 0 ? std::fabs(d->vprob) + std::fabs(d->vwidth)
                                    : std::fabs(d->vprob) + 6 * std::fabs(d->vwidth)) / d->unit_km;
     }
-    if ((rc = order_on_device(h, vmax * vmax, nullptr, 0))) return rc;
-    if (soa_out) HIPCHK(hipMemcpyAsync(soa_out, h->d_packets, bytes, hipMemcpyDeviceToHost, h->stream));
+    // (a set made of pieces may mix sources: let the device find its largest launch speed)
+    if ((rc = order_on_device(h, d->dest_total > 0 ? -1.0 : vmax * vmax, nullptr, 0))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
     });
@@ -1891,7 +1965,7 @@ int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs)
     if (e == hipSuccess) e = hipEventCreate(&b);
     for (int r = 0; r <= reps && e == hipSuccess; r++) {         // first round warms up
         e = hipEventRecord(a, h->stream);
-        hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)(h->n_cu * 16)), dim3(NXC_BLOCK), 0, h->stream,
+        hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)(h->n_cu * 32)), dim3(NXC_BLOCK), 0, h->stream,
                            reinterpret_cast<const nxc_v2d *>(buf),
                            reinterpret_cast<nxc_v2d *>(buf + (size_t)n16 * 16), n16);
         if (e == hipSuccess) e = hipGetLastError();
@@ -1936,6 +2010,33 @@ int nxc_shader_clock_mhz(nxc_handle *h, double *mhz)
     if (f.empty()) return fail(NXC_ERR_HIP, "no clock stamps came back");
     std::nth_element(f.begin(), f.begin() + f.size() / 2, f.end());
     *mhz = f[f.size() / 2];
+    return NXC_OK;
+    });
+}
+
+int nxc_pcg64_uniforms(nxc_handle *h, const uint64_t state[2], const uint64_t inc[2], int64_t n,
+                       int64_t row0, int64_t count, int32_t nvec, double *out)
+{
+    return guarded([&]() -> int {
+    if (!h || !state || !inc || !out || n < 1 || row0 < 0 || count < 1 || row0 + count > n ||
+        nvec < 1 || nvec > NXC_PCG_VECS || n >= ((int64_t)1 << (NXC_PCG_BITS - 1)) || !(inc[1] & 1ull))
+        return fail(NXC_ERR_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const std::vector<u128> maps = pcg_tables(((u128)inc[0] << 64) | inc[1], n);
+    const size_t map_bytes = maps.size() * sizeof(u128), out_bytes = (size_t)nvec * count * 8;
+    int rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, map_bytes + out_bytes);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(h->d_scratch);
+    HIPCHK(hipMemcpyAsync(base, maps.data(), map_bytes, hipMemcpyHostToDevice, h->stream));
+    PcgK P{};
+    P.state = ((u128)state[0] << 64) | state[1];
+    P.row0 = row0;
+    P.maps = reinterpret_cast<const nxc_u128 *>(base);
+    hipLaunchKernelGGL(k_pcg_uniforms, dim3(flat_grid(h, count, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+                       h->stream, P, (int)nvec, count, reinterpret_cast<double *>(base + map_bytes));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, base + map_bytes, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return NXC_OK;
     });
 }

@@ -645,9 +645,20 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_stream_copy(const nxc_v2d *__restrict__ src, nxc_v2d *__restrict__ dst, int64_t n16)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
-         i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    // four independent 16-byte loads in flight per lane before the first store
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const nxc_v2d a = __builtin_nontemporal_load(src + i);
+        const nxc_v2d b = __builtin_nontemporal_load(src + i + stride);
+        const nxc_v2d c = __builtin_nontemporal_load(src + i + 2 * stride);
+        const nxc_v2d d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // Shader clock under fp64 load: every wave runs `iters` rounds of eight independent fp64 fma
@@ -813,6 +824,43 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
 // is the same whatever the launch geometry or the number of GPUs.  The reference's sampler uses
 // NumPy's PCG64 stream, so parity with it is statistical (KS tests); parity with the oracle's
 // NumPy Philox restatement is to rounding of sin/cos/asin/log.
+// NumPy's PCG64 on the device (numpy/random/src/pcg64/pcg64.h: 128-bit LCG, XSL-RR output; a
+// double is (next64 >> 11) * 2^-53 and consumes exactly one output).  The reference draws whole
+// vectors one after the other (Output.py:138-139; source_distribution.py:51-62,169-171,202-212),
+// so element `row` of draw `vec` of a chunk of `n` packets is output number vec*n + row of the
+// stream, i.e. the state after vec*n + row + 1 steps.  A thread jumps there in two moves: to
+// row + 1 with the precomputed affine maps of 2^b steps (one 128-bit multiply-add per set bit),
+// then by vec*n with that vector's map.  All maps come from the host (nxc_api.hip: pcg_tables).
+typedef unsigned __int128 nxc_u128;
+constexpr int NXC_PCG_BITS = 40;       // rows below 2^40
+constexpr int NXC_PCG_VECS = 8;        // draws per packet
+struct PcgK {
+    nxc_u128 state;                    // after seeding: PCG64(seed).state['state']['state']
+    long long row0;                    // row of this call's first packet inside its chunk's draws
+    const nxc_u128 *maps;              // [NXC_PCG_BITS + NXC_PCG_VECS][2]: {multiplier, increment}
+};
+
+NXC_DEV nxc_u128 pcg_row_state(const PcgK &P, long long row)
+{
+    nxc_u128 s = P.state;
+    unsigned long long d = (unsigned long long)(P.row0 + row) + 1ull;
+    for (int b = 0; d != 0; b++, d >>= 1)
+        if (d & 1ull) s = P.maps[2 * b] * s + P.maps[2 * b + 1];
+    return s;
+}
+
+// the uniform of draw `vec` for the packet whose row state is s
+NXC_DEV double pcg_uniform(const PcgK &P, nxc_u128 s, int vec)
+{
+    const nxc_u128 *m = P.maps + 2 * (NXC_PCG_BITS + vec);
+    const nxc_u128 t = m[0] * s + m[1];
+    const unsigned long long hi = (unsigned long long)(t >> 64), lo = (unsigned long long)t;
+    const unsigned rot = (unsigned)(hi >> 58);                      // state >> 122
+    const unsigned long long x = hi ^ lo;
+    const unsigned long long r = (x >> rot) | (x << ((64u - rot) & 63u));
+    return (double)(r >> 11) * 0x1p-53;
+}
+
 struct SourceK {
     double endtime, exobase, sinlat0, sinlat1, lon0, lon1, vprob, vwidth, unit_km;
     double sinalt0, sinalt1, az0, az1;
@@ -822,7 +870,22 @@ struct SourceK {
     int spatial_type, n_speed, map_nlon, map_nlat;
     double map_max;                      // accept/reject ceiling = max of the density map
     const double *speed_cdf, *speed_v, *map;
+    int generator, pad_;                 // 0 = Philox-4x32-10, 1 = NumPy's PCG64 stream
+    PcgK pcg;
+    long long stride, offset;            // the packets go to soa[c * stride + offset + i]
 };
+
+// diagnostics: out[vec][i] = uniform of draw `vec` for row i (the parity test compares them with
+// numpy.random.default_rng(seed).random(n) bit for bit)
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_pcg_uniforms(PcgK P, int nvec, int64_t count, double *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const nxc_u128 s = pcg_row_state(P, i);
+        for (int v = 0; v < nvec; v++) out[v * count + i] = pcg_uniform(P, s, v);
+    }
+}
 
 // np.interp(x, xp, fp) for a non-decreasing xp in global memory: bisection for the last node
 // <= x, then slope*(x - xp[j]) + fp[j] (numpy compiled_base.c arr_interp).
@@ -868,10 +931,25 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long gi = (unsigned long long)(K.first_index + i);
-        double ut, ulat, ulon, uspd, ualt, uaz;
-        philox_pair(gi, 0, NXC_STREAM_SOURCE, K.seed, ut, ulat);
-        philox_pair(gi, 1, NXC_STREAM_SOURCE, K.seed, ulon, uspd);
-        philox_pair(gi, 2, NXC_STREAM_SOURCE, K.seed, ualt, uaz);
+        double ut = 0.0, ulat, ulon, uspd, ualt = 0.0, uaz = 0.0;
+        if (K.generator == 1) {
+            // the reference's draw order: [launch time] sin(latitude), longitude, speed,
+            // [sin(altitude), azimuth] -- each a whole vector of the stream
+            const nxc_u128 st = pcg_row_state(K.pcg, i);
+            int v = 0;
+            if (K.random_time) ut = pcg_uniform(K.pcg, st, v++);
+            ulat = pcg_uniform(K.pcg, st, v++);
+            ulon = pcg_uniform(K.pcg, st, v++);
+            uspd = pcg_uniform(K.pcg, st, v++);
+            if (K.angular_type != 0) {
+                ualt = pcg_uniform(K.pcg, st, v++);
+                uaz = pcg_uniform(K.pcg, st, v++);
+            }
+        } else {
+            philox_pair(gi, 0, NXC_STREAM_SOURCE, K.seed, ut, ulat);
+            philox_pair(gi, 1, NXC_STREAM_SOURCE, K.seed, ulon, uspd);
+            philox_pair(gi, 2, NXC_STREAM_SOURCE, K.seed, ualt, uaz);
+        }
         const double time = K.random_time ? ut * K.endtime : K.endtime;       // Output.py:136-139
         double lat, lon;
         if (K.spatial_type == 0) {                                             // uniform :51-62
@@ -922,10 +1000,11 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict
         const double dx = (v_t0 * (n0 / nn) + v_t1 * (y0 / en)) + v_rad * (x0 / rn);   // :247-248
         const double dy = (v_t0 * (n1 / nn) + v_t1 * (-x0 / en)) + v_rad * (y0 / rn);
         const double dz = (v_t0 * (n2 / nn) + v_t1 * 0.0) + v_rad * (z0 / rn);
-        soa[0 * n + i] = time;
-        soa[1 * n + i] = x0; soa[2 * n + i] = y0; soa[3 * n + i] = z0;
-        soa[4 * n + i] = dx * v; soa[5 * n + i] = dy * v; soa[6 * n + i] = dz * v;
-        soa[7 * n + i] = 1.0;
+        double *__restrict__ dst = soa + K.offset + i;
+        dst[0] = time;
+        dst[1 * K.stride] = x0; dst[2 * K.stride] = y0; dst[3 * K.stride] = z0;
+        dst[4 * K.stride] = dx * v; dst[5 * K.stride] = dy * v; dst[6 * K.stride] = dz * v;
+        dst[7 * K.stride] = 1.0;
     }
     flush_counter(&ctr->unfinished, my_unfinished);
 }

@@ -31,7 +31,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
            'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info',
-           'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz')
+           'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms')
 ABI_VERSION = 2
 
 
@@ -69,7 +69,10 @@ class nxc_source_desc(C.Structure):
                [(k, C.c_int32) for k in ('random_time', 'speed_type', 'angular_type', 'is_planet')] + \
                [('seed', C.c_uint64), ('first_index', C.c_int64), ('spatial_type', C.c_int32),
                 ('reserved', C.c_int32), ('n_speed', C.c_int64), ('speed_cdf', _dp),
-                ('speed_v', _dp), ('map_nlon', C.c_int64), ('map_nlat', C.c_int64), ('map', _dp)]
+                ('speed_v', _dp), ('map_nlon', C.c_int64), ('map_nlat', C.c_int64), ('map', _dp),
+                ('generator', C.c_int32), ('reserved2', C.c_int32), ('pcg_state', C.c_uint64*2),
+                ('pcg_inc', C.c_uint64*2), ('pcg_n', C.c_int64), ('pcg_row0', C.c_int64),
+                ('dest_offset', C.c_int64), ('dest_total', C.c_int64)]
 
 
 class nxc_bounce_desc(C.Structure):
@@ -118,6 +121,15 @@ def load_library():
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def pcg64_words(seed):
+    """(state, inc) of numpy.random.default_rng(seed)'s bit generator as {high, low} 64-bit words
+    (what nxc_source_desc.pcg_state / pcg_inc take)."""
+    st = np.random.PCG64(seed).state['state']
+    mask = (1 << 64) - 1
+    return ((C.c_uint64*2)(st['state'] >> 64, st['state'] & mask),
+            (C.c_uint64*2)(st['inc'] >> 64, st['inc'] & mask))
 
 
 def _p(a):
@@ -366,16 +378,24 @@ class Context:
         self.n_packets = soa.shape[1]
 
     def sample_packets(self, n, seed, first_index=0, download=False, speed_table=None,
-                       surface_map=None, **src):
+                       surface_map=None, pcg64=None, piece=None, **src):
         """Draw n initial states on the device (nxc_packets_sample).  ``src``: the scalar fields
         of nxc_source_desc except seed/first_index; ``speed_table`` = (cdf, speeds [km/s]) for
         speed_type 2; ``surface_map`` = density array [nlon, nlat] for spatial_type 1 (see
-        Output.source_desc)."""
+        Output.source_desc).  ``pcg64 = (npackets, row0)``: the reference's own seeded stream --
+        rows row0 .. row0 + n - 1 of the npackets-long vectors default_rng(seed) would draw.
+        ``piece = (offset, total)``: the n packets are part of a resident set of ``total`` that
+        several calls fill in ascending order."""
         d = nxc_source_desc()
         for k, v in src.items():
             setattr(d, k, v)
         d.seed = int(seed) & 0xffffffffffffffff
         d.first_index = int(first_index)
+        if pcg64 is not None:
+            d.generator, d.pcg_n, d.pcg_row0 = 1, int(pcg64[0]), int(pcg64[1])
+            d.pcg_state, d.pcg_inc = pcg64_words(seed)
+        if piece is not None:
+            d.dest_offset, d.dest_total = int(piece[0]), int(piece[1])
         keep = []
         if speed_table is not None:
             cdf, speeds = _f64(speed_table[0]), _f64(speed_table[1])
@@ -390,7 +410,7 @@ class Context:
         out = np.empty((8, int(n))) if download else None
         self._check(self.lib.nxc_packets_sample(self._h, C.byref(d), C.c_int64(int(n)),
                                                 _p(out) if download else None))
-        self.n_packets = int(n)
+        self.n_packets = int(n) if piece is None else int(piece[1])
         return out
 
     def image_clear(self):
@@ -612,6 +632,15 @@ class Context:
         return float(mhz.value)
 
     # -- diagnostics ------------------------------------------------------------------------
+    def pcg64_uniforms(self, seed, n, row0, count, nvec):
+        """(nvec, count): rows row0.. of the first nvec ``default_rng(seed).random(n)`` vectors,
+        as the device sampler's generator 1 forms them."""
+        state, inc = pcg64_words(seed)
+        out = np.empty((nvec, count))
+        self._check(self.lib.nxc_pcg64_uniforms(self._h, state, inc, C.c_int64(n), C.c_int64(row0),
+                                                C.c_int64(count), C.c_int32(nvec), _p(out)))
+        return out
+
     def math(self, which, x, y=None):
         code = {'exp': 0, 'log': 1, 'cube': 2, 'sqrt': 3, 'div': 4}[which]
         x = _f64(x)

@@ -543,3 +543,70 @@ def test_batched_input_run_equals_output_by_output(ctx, mode, tmp_path):
         np.testing.assert_allclose(resident.image, host.image, rtol=1e-12, atol=0)
         one_img = one.produce_image(params, context=ctx)
         assert np.array_equal(one_img.packet_image, host.packet_image)
+
+
+def test_device_pcg64_follows_the_seeded_host_stream(ctx):
+    """generator='pcg64' (nxc_source_desc.generator = 1): the device jumps into NumPy's PCG64
+    stream (Output.py:92; the reference draws whole random(npackets) vectors one after the other,
+    source_distribution.py:51-62,169-171,202-212) instead of using its own Philox counters.
+    The uniforms are bit-equal to default_rng(seed).random(n), window by window; X0 equals the
+    host sampler's to libm rounding; the packet-count image of a 2e4-packet run is the
+    host-sampled run's; shards and Input.run follow."""
+    # 1. the raw uniforms: six successive vectors, whole and windows, small and bench-sized n
+    for seed, n, row0, count in ((1234, 1000, 0, 1000), (1234, 1000, 123, 754), (7, 1, 0, 1),
+                                 (99, 10_000_000, 0, 4096), (99, 10_000_000, 9_990_000, 10_000),
+                                 (2**63 + 5, 20_000_000, 12_345_678, 3000)):
+        rng = np.random.default_rng(seed)
+        got = ctx.pcg64_uniforms(seed, n, row0, count, 6)
+        for v in range(6):
+            assert np.array_equal(got[v], rng.random(n)[row0:row0 + count]), (seed, n, v)
+    # 2. X0: constant-step (five vectors) and variable-step (launch times first) sources
+    eps = np.finfo(float).eps
+    for variable in (False, True):
+        inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+        if variable:
+            inputs.options.step_size = 0.
+            inputs.options.resolution = 1e-4
+        n, seed = 20000, 321
+        with contextlib.redirect_stdout(io.StringIO()):
+            host = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx)
+            dev = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
+                         sampler='device', generator='pcg64')
+            part = Output(inputs, n, seed=seed, integrate=False, save=False, context=ctx,
+                          sampler='device', generator='pcg64', window=(n, 777, 15001))
+        speed = host.X0.v.values.max()
+        for c in ('time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac'):
+            a, b = dev.X0[c].values, host.X0[c].values
+            scale = speed if c.startswith('v') else (1.0 if c in 'xyz' else np.abs(b).max())
+            assert np.abs(a - b).max() <= 4*eps*scale, (c, np.abs(a - b).max()/eps/scale)
+            assert np.array_equal(part.X0[c].values, a[777:15001]), c      # a window = a slice
+        assert (dev.X0.x.values == host.X0.x.values).mean() > 0.5           # mostly the same bits
+        if variable:
+            assert np.array_equal(dev.X0.time.values, host.X0.time.values)  # u * endtime: no libm
+    # 3. the run: host-sampled vs device-sampled packets through the streaming image
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    params = {'quantity': 'radiance', 'dims': '128,128'}
+    kw = dict(npackets=20000, seed=55, packs_per_it=8000, context=ctx)
+    with contextlib.redirect_stdout(io.StringIO()):
+        host_img = ModelImage(inputs, params, sampler='numpy', **kw)
+        dev_img = ModelImage(inputs, params, sampler='device', generator='pcg64', **kw)
+        shards = [ModelImage(inputs, params, sampler='device', generator='pcg64', finalize=False,
+                             shard=s, **kw) for s in ((0, 6001), (6001, 14444), (14444, 20000))]
+    assert host_img.packet_image.sum() > 1e6
+    assert np.array_equal(dev_img.packet_image, host_img.packet_image)
+    np.testing.assert_allclose(dev_img.image, host_img.image, rtol=1e-9, atol=0)
+    assert dev_img.counters['particle_steps'] == host_img.counters['particle_steps']
+    assert np.array_equal(sum(s.packet_image for s in shards), host_img.packet_image)
+    # 4. Input.run: Output k follows default_rng(seed + k), all Outputs in one launch
+    runs = {}
+    for sampler in ('numpy', 'device'):
+        inp = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+        inp.options.endtime = type(inp.options.endtime)(6000., 's')
+        with contextlib.redirect_stdout(io.StringIO()):
+            inp.run(5000, packs_per_it=2000, seed=8, context=ctx, sampler=sampler,
+                    **({'generator': 'pcg64'} if sampler == 'device' else {}))
+        runs[sampler] = inp
+    for a, b in zip(runs['numpy']._catalogue, runs['device']._catalogue):
+        np.testing.assert_allclose(b.X0.x.values, a.X0.x.values, rtol=0, atol=1e-6)   # float32 now
+        assert len(a.X) == len(b.X) and np.array_equal(a.X.Index.values, b.X.Index.values)
+        np.testing.assert_allclose(b.X.x.values, a.X.x.values, rtol=0, atol=1e-5)
