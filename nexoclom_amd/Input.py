@@ -146,6 +146,9 @@ class Input:
         if together and context is None:
             from . import hip_api
             context = hip_api.Context(device)
+        if seed is None and sampler == 'device':
+            from .Output import fresh_key
+            seed = fresh_key()                   # one key for the whole (unseeded) run
         while have < want:
             todo = want - have
             size = min(todo, self.chunk_size(packs_per_it))
@@ -189,7 +192,7 @@ class Input:
                                 download=True, pcg64=(size, 0), piece=(g*size, whole), **src))
                     elif sampler == 'device':
                         lead = outs[0]
-                        soa = context.sample_packets(size*len(outs), 0 if seed is None else seed,
+                        soa = context.sample_packets(size*len(outs), seed,
                                                      lead._first_index, download=True,
                                                      **lead.source_desc())
                         for g, out in enumerate(outs):

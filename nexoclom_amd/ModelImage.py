@@ -271,6 +271,12 @@ class ModelImage(ModelResult):
                                       'variable-step driver keeps one final row per packet')
         hi = total if hi is None else hi
         ctx = self.context()
+        if seed is None and sampler == 'device':
+            # an unseeded run: one fresh key for all its chunks (recorded; default_rng(None) of
+            # the host sampler is entropy-seeded too), not the same key 0 for every run
+            from .Output import fresh_key
+            seed = fresh_key()
+        self.seed = seed
         chunk = int(packs_per_it) if packs_per_it else max(1, min(total, 20_000_000))
         nsteps, n_iter = n_output_steps(opt.endtime.value, float(opt.step_size))
         first = True

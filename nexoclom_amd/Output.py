@@ -45,6 +45,13 @@ NARROW = {np.int64: np.int32, np.float64: np.float32}
 WIDE = {np.int32: np.int64, np.float32: np.float64}
 
 
+def fresh_key():
+    """A 64-bit key for the counter-based device generators of an UNSEEDED run, from the
+    operating system's entropy like numpy.random.default_rng(None) (Output.py:92): two unseeded
+    runs must not integrate identical packets."""
+    return int(np.random.SeedSequence().entropy) & 0xffffffffffffffff
+
+
 def n_output_steps(endtime, step):
     """nsteps (Output.py:375) and the number of iterations of the ``while curtime > 0`` loop
     (Output.py:384,431), evaluated with the same float arithmetic."""
@@ -126,8 +133,11 @@ class Output:
 
             # surface accommodation / sticking set-up when packets do not simply stick
             # (Output.py:130-133); None = absorbed on impact
+            # key of the device's counter-based draws (initial states, re-emission): the seed, or
+            # for an unseeded run a fresh one, kept on the Output so that the run can be repeated
+            self.device_key = fresh_key() if seed is None else int(seed)
             from .surface import bounce_config
-            self._bounce = bounce_config(inputs, self.GM, self.unit_km, seed)
+            self._bounce = bounce_config(inputs, self.GM, self.unit_km, self.device_key)
             self._first_index = first_index
 
             self.npackets = npackets
@@ -159,7 +169,7 @@ class Output:
                 # presampled: the caller drew this Output's packets as part of a larger device call
                 # (Input.run takes all its chunks in one go)
                 soa = None if presampled else self.context().sample_packets(
-                    npackets, 0 if seed is None else seed, first_index,
+                    npackets, self.device_key, first_index,
                     download=materialize_x0, **self.stream_window(seed, window),
                     **self.source_desc())
                 self._resident = not presampled

@@ -1462,7 +1462,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         if (!(d->speed_cdf[d->n_speed - 1] > d->speed_cdf[0]))
             return fail(NXC_ERR_ARG, "nxc_source_desc: speed_cdf is flat");
     }
-    double map_max = 0.0;
+    double map_max = 0.0, map_sum = 0.0;
     if (spot) {
         if (d->map_nlon < 2 || d->map_nlat < 2 || d->map_nlon > 8192 || d->map_nlat > 8192 || !d->map)
             return fail(NXC_ERR_ARG, "nxc_source_desc: surface spot needs a density map");
@@ -1470,6 +1470,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
             if (!(d->map[k] >= 0.0) || !std::isfinite(d->map[k]))
                 return fail(NXC_ERR_ARG, "nxc_source_desc: density map values must be finite and >= 0");
             map_max = std::max(map_max, d->map[k]);
+            map_sum += d->map[k];
         }
         if (!(map_max > 0.0)) return fail(NXC_ERR_ARG, "nxc_source_desc: density map is all zero");
     }
@@ -1513,6 +1514,15 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     K.spatial_type = d->spatial_type; K.n_speed = (int)n_sp;
     K.map_nlon = spot ? (int)d->map_nlon : 0; K.map_nlat = spot ? (int)d->map_nlat : 0;
     K.map_max = map_max;
+    K.max_trials = NXC_SPOT_MIN_TRIALS;
+    if (spot && map_sum > 0) {
+        // acceptance rate of the uniform (lon, lat) proposal = mean / max of the map: a narrow spot
+        // (sigma 0.05 rad: 8e-4) needs tens of thousands of trials for the unluckiest of 1e6 packets
+        const double accept = map_sum / (double)(d->map_nlon * d->map_nlat) / map_max;
+        const double want = 32.0 / accept;
+        K.max_trials = want > (double)NXC_SPOT_MAX_TRIALS ? NXC_SPOT_MAX_TRIALS
+                       : (want < (double)NXC_SPOT_MIN_TRIALS ? NXC_SPOT_MIN_TRIALS : (int)want);
+    }
     K.speed_cdf = h->d_source; K.speed_v = h->d_source + n_sp; K.map = h->d_source + 2 * n_sp;
     K.generator = d->generator;
     if (pcg) {       // (pcg excludes the tabulated sources, so the maps sit at the buffer's start)

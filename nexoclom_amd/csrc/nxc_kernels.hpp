@@ -870,7 +870,7 @@ struct SourceK {
     int spatial_type, n_speed, map_nlon, map_nlat;
     double map_max;                      // accept/reject ceiling = max of the density map
     const double *speed_cdf, *speed_v, *map;
-    int generator, pad_;                 // 0 = Philox-4x32-10, 1 = NumPy's PCG64 stream
+    int generator, max_trials;                 // 0 = Philox-4x32-10, 1 = NumPy's PCG64 stream
     PcgK pcg;
     long long stride, offset;            // the packets go to soa[c * stride + offset + i]
 };
@@ -920,7 +920,10 @@ NXC_DEV double map_bilinear(const SourceK &K, double lon, double lat)
            (tx * (1.0 - ty) * row1[0] + tx * ty * row1[1]);
 }
 
-constexpr int NXC_SPOT_MAX_TRIALS = 4096;   // a packet that never passes keeps its last candidate
+// Rejection trials per packet: the host sizes the budget to the map (32 / acceptance rate, so that
+// a packet fails to find a launch point with probability e^-32) between these bounds; a packet
+// that never passes is reported, and the call fails.
+constexpr int NXC_SPOT_MIN_TRIALS = 4096, NXC_SPOT_MAX_TRIALS = 1 << 18;
 constexpr unsigned NXC_SPOT_BLOCK0 = 16;    // Philox draw blocks 16 + 2t, 17 + 2t of trial t
 
 __global__ void __launch_bounds__(NXC_BLOCK)
@@ -958,7 +961,7 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict
         } else {                                                               // surface spot :96-118
             bool accepted = false;
             lon = 0.0; lat = 0.0;
-            for (int t = 0; t < NXC_SPOT_MAX_TRIALS && !accepted; t++) {
+            for (int t = 0; t < K.max_trials && !accepted; t++) {
                 double ux, uy, uf, unused;
                 philox_pair(gi, NXC_SPOT_BLOCK0 + 2u * (unsigned)t, NXC_STREAM_SOURCE, K.seed, ux, uy);
                 philox_pair(gi, NXC_SPOT_BLOCK0 + 2u * (unsigned)t + 1u, NXC_STREAM_SOURCE, K.seed,

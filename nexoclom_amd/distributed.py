@@ -348,6 +348,10 @@ def sharded_image(inputs, params, npackets, seed, cp=None, device=None, downcast
     if context is None:
         from . import hip_api
         context = hip_api.Context(pick_device(cp, device))
+    if seed is None and sampler == 'device':
+        # an unseeded run still is ONE run: every rank uses rank 0's fresh key
+        from .Output import fresh_key
+        seed = int.from_bytes(cp.bcast_bytes(fresh_key().to_bytes(8, 'little'), 8), 'little')
     lo, hi = shard_range(int(npackets), cp.rank, cp.world)
     img = ModelImage(inputs, params, npackets=int(npackets), shard=(lo, hi), seed=seed,
                      context=context, downcast=downcast, sampler=sampler,

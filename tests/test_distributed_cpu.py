@@ -78,6 +78,17 @@ def _worker(rank, world, port, tmpdir, kind):
             assert np.array_equal(whole.packet_image, part.packet_image), sampler
             np.testing.assert_allclose(part.image, whole.image, rtol=1e-12, atol=0)
             np.save(os.path.join(tmpdir, f'{sampler}.npy'), part.packet_image)
+    # an unseeded device-sampled run is still one run: every rank integrates under rank 0's fresh
+    # key (recorded on the image), and two such runs do not repeat each other
+    keys = []
+    for _ in range(2):
+        ctx = OracleContext()
+        with contextlib.redirect_stdout(io.StringIO()):
+            img = sharded_image(inputs, PARAMS, 300, None, cp=cp, context=ctx, sampler='device',
+                                packs_per_it=CHUNK, reduce='host')
+        assert cp.allgather_bytes(str(img.seed).encode()) == [str(img.seed).encode()]*world
+        keys.append(img.seed)
+    assert keys[0] != keys[1] and all(0 <= k < 2**64 for k in keys)
     cp.barrier()
     cp.close()
     if rank == 0:

@@ -493,9 +493,24 @@ def test_device_sampler_refuses_unusable_tables(ctx):
     spike = np.zeros((361, 181)); spike[100, 90] = 1.0          # one node of 65 341
     with pytest.raises(hip_api.HipError, match='no launch point'):
         ctx.sample_packets(20000, 1, **dict(src, surface_map=spike))
+    # the failed call left no packets behind (its never-accepted candidates are not a resident set)
+    with pytest.raises(hip_api.HipError, match='no resident packets'):
+        ctx.integrate_const(30., 10, 25.)
     # a usable call afterwards still works on the same handle
     X = ctx.sample_packets(1000, 1, download=True, **src)
     assert np.isfinite(X).all() and np.allclose(np.linalg.norm(X[1:4], axis=0), 1.0)
+    # a narrow spot (sigma 0.05 rad: the uniform proposal is accepted 8 times in 10 000) needs far
+    # more than a fixed few thousand trials for the unluckiest of many packets: the budget follows
+    # the map's acceptance rate, and the packets land around the spot
+    from nexoclom_amd.source_distribution import spot_density_map
+    lon0, lat0 = 1.0, 0.3
+    _, _, narrow = spot_density_map(lon0, lat0, 0.05)
+    X = ctx.sample_packets(300000, 5, download=True, **dict(src, surface_map=narrow))
+    # (the reference's map is built with -sin(lat) for z, source_distribution.py:96-113: the spot
+    # sits at latitude -lat0)
+    centre = np.array([np.sin(lon0)*np.cos(lat0), -np.cos(lon0)*np.cos(lat0), -np.sin(lat0)])
+    far = np.arccos(np.clip(centre @ X[1:4], -1, 1))
+    assert np.isfinite(X).all() and np.median(far) < 0.12 and (far < 0.5).mean() > 0.99
 
 
 @pytest.mark.parametrize('mode', ['constant', 'variable', 'device-sampled'])

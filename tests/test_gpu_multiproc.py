@@ -36,10 +36,18 @@ def _launch(world, npackets, seed, sampler):
                                        'host'], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     lines = []
-    for p in procs:
-        out, err = p.communicate(timeout=240)
-        assert p.returncode == 0, err[-2000:]
-        lines.append(json.loads(out.strip().splitlines()[-1]))
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=240)
+            assert p.returncode == 0, err[-2000:]
+            lines.append(json.loads(out.strip().splitlines()[-1]))
+    finally:
+        # a rank that failed or timed out must not leave its peers behind: each holds a HIP
+        # context on the one GPU and would sit in the control plane until its own timeout
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
     return lines
 
 
