@@ -341,12 +341,22 @@ def run_rank(args, cp, make_context, emit=print):
         job_barrier(comm)
         ctx.synchronize()
         t0 = time.perf_counter()
-        ctx.upload_soa(x0)                  # H2D of 64 B/packet + on-device queue ordering
-        ctx.set_first_index(a)
-        one_step(comm)
+        if variable:
+            ctx.upload_soa(x0)              # H2D of 64 B/packet + on-device queue ordering
+            one_step(comm)
+        else:
+            # the pipelined pass: piece p + 1 crosses PCIe and is ordered while piece p is integrated
+            ctx.image_clear()
+            ctx.integrate_const_streamed(x0, opt.step_size, n_iter, opt.outeredge, image=True)
+            if comm:
+                ctx.image_allreduce()
         ctx.synchronize()
         job_barrier(comm)
         incl.append(time.perf_counter() - t0)
+    if not variable:
+        ctr_incl = ctx.counters()
+        assert ctr_incl['particle_steps'] == ctr['particle_steps'], 'the streamed pass is another run'
+        ctx.set_first_index(a)
     incl_s = min(incl)
     if comm:
         incl_s = ctx.allreduce_max(incl_s)

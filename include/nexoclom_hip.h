@@ -323,6 +323,15 @@ int nxc_image_accumulate_rows(nxc_handle *h, const nxc_rows *r, int64_t first, i
 int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double outeredge,
                               uint32_t flags);
 
+/* Upload + integrate as one pipelined pass ("incl. H2D of X0"): the n
+ * packets of host array soa0 [8][n] are cut into `pieces` (1..32); piece p + 1 crosses PCIe and is
+ * put into queue order while piece p is integrated.  Asynchronous like nxc_integrate_const_async
+ * (soa0 must stay valid until nxc_synchronize); afterwards the packets are the resident set, the
+ * image holds their samples and nxc_counters_get reports the pass.  Same results as
+ * nxc_packets_upload + nxc_integrate_const_async (the order of the queue changes no packet). */
+int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, int32_t pieces,
+                                 double step, int64_t n_iter, double outeredge, uint32_t flags);
+
 /* ---- a-4: variable-step driver over the resident packets ---------------------------------------
  * final_out host [8][n]; hstore_out (nullable) host [n] = stored step_size column at exit. */
 int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,

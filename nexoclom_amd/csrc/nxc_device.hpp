@@ -419,6 +419,7 @@ struct LoopK {
     unsigned long long *head;
     long long n;
     const long long *offsets;     // ROWS pass: row offsets per packet index
+    const unsigned long long *avail;   // streamed upload: queue positions published so far (null: all)
 };
 // Refined reciprocals of the two launch-constant divisors of the weight (1e6, Apix), computed once
 // per workgroup; read from LDS by the samples that fall inside the image.

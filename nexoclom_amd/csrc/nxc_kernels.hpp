@@ -88,13 +88,14 @@ NXC_DEV void stage_tables(const unsigned char *__restrict__ blob, int64_t bytes)
 NXC_DEV void stage_tables_and_args(const unsigned char *__restrict__ blob, int64_t bytes,
                                    const double *soa0, const unsigned *order, double *final_out,
                                    long long *steps_out, unsigned long long *head, long long n,
-                                   const long long *offsets = nullptr)
+                                   const long long *offsets = nullptr,
+                                   const unsigned long long *avail = nullptr)
 {
     stage_tables(blob, bytes);
     if (threadIdx.x == 0) {
         LoopK &L = lds_header_rw().L;
         L.soa0 = soa0; L.order = order; L.final_out = final_out; L.steps_out = steps_out;
-        L.head = head; L.n = n; L.offsets = offsets;
+        L.head = head; L.n = n; L.offsets = offsets; L.avail = avail;
     }
     __syncthreads();
 }
@@ -282,10 +283,40 @@ k_rows_densify(const double *__restrict__ rec, const long long *__restrict__ off
 // The claim for the NEXT chunk is issued as soon as the current one is loaded, so the returning
 // atomic's round trip runs under that chunk's packets; a wave leaves only after the claim it
 // holds turned out to lie beyond the queue's end, so no claimed chunk is ever dropped.
+// Streamed upload (nxc_integrate_const_streamed): the queue is still being filled while the kernel
+// runs -- pieces of it cross PCIe, are put into queue order by small kernels on another stream, and
+// are then PUBLISHED: *avail = number of queue positions that are ready (k_publish: release store at
+// agent scope after the producing kernels have completed).  A wave that claimed positions beyond
+// that waits here (acquire load at agent scope, s_sleep between polls).  Bounded: the host
+// publishes ~0 when it gives up, and a wave that has waited three seconds of s_memrealtime
+// (100 MHz) gives up itself; either way the wave treats the queue as drained and the launch is
+// reported as unfinished.
+NXC_DEV bool wait_published(const unsigned long long *avail, unsigned long long need)
+{
+    unsigned long long t0 = 0;
+    bool timing = false;
+    for (;;) {
+        const unsigned long long v =
+            __hip_atomic_load(avail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == ~0ull) return false;
+        if (v >= need) return true;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (!timing) { t0 = now; timing = true; }
+        else if (now - t0 > 300000000ull) return false;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+__global__ void k_publish(unsigned long long *avail, unsigned long long value)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(avail, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct WaveQueue {
     long long pending = 0;      // lane 0: queue position claimed for the next reload
     int c_pos = 0, c_cnt = 0;
-    bool drained = false;
+    bool drained = false, stalled = false;
 
     NXC_DEV void start()
     {
@@ -317,6 +348,12 @@ struct WaveQueue {
                 if (b >= n) { drained = true; break; }
                 c_cnt = (b + NXC_CHUNK <= n) ? NXC_CHUNK : (int)(n - b);
                 c_pos = 0;
+                if (const unsigned long long *avail = L.avail) {      // streamed upload
+                    if (!wait_published(avail, (unsigned long long)(b + c_cnt))) {
+                        drained = true; stalled = true; c_cnt = 0;
+                        break;
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane < c_cnt) {
                     const long long src = b + lane;
@@ -368,11 +405,12 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               double edge2, double *__restrict__ final_out,
               long long *__restrict__ steps_out, double *__restrict__ acc2,
               DevCounters *__restrict__ ctr, const double *__restrict__ moon_pos = nullptr,
-              const long long *__restrict__ offsets = nullptr, void *__restrict__ rec = nullptr)
+              const long long *__restrict__ offsets = nullptr, void *__restrict__ rec = nullptr,
+              const unsigned long long *__restrict__ avail = nullptr)
 {
     static_assert(!(IMAGE && ROWS), "the rows pass has no image");
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n,
-                          offsets);
+                          offsets, avail);
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
@@ -406,7 +444,13 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = nxc_stamp();
 #endif
     for (;;) {
+#ifdef NXC_REFILL_MIN      /* experiment: hand out packets only once this many lanes are free */
+        const unsigned long long free_ = __ballot(!has);
+        const bool serve = __popcll(free_) >= NXC_REFILL_MIN || free_ == ~0ull;
+        const long long got = serve ? q.refill<ROWS != 0>(!has, stage_off, s, &row0, &nrow) : -1;
+#else
         const long long got = q.refill<ROWS != 0>(!has, stage_off, s, &row0, &nrow);
+#endif
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; lossfrac = 0.0; }
         if (__ballot(has) == 0) break;
         NXC_STAMP(0);                                  // refill
@@ -514,6 +558,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     }
     flush_counter(&ctr->particle_steps, my_steps);
     if (ROWS) flush_counter(&ctr->unfinished, my_overrun);
+    if (!ROWS && q.stalled && (threadIdx.x & 63) == 0) atomicAdd(&ctr->unfinished, 1ull);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
         flush_counter(&ctr->samples_binned, my_binned);
@@ -1013,6 +1058,8 @@ k_sample(SourceK K, int64_t n, double *__restrict__ soa, DevCounters *__restrict
 }
 
 // Queue order on the device: counting sort of the packet indices by decreasing |v|^2.
+// The packets are `n` rows of an array whose columns are `stride` apart (a whole resident set:
+// stride = n; a piece of one that is still being uploaded: stride = the set's size).
 constexpr int NXC_ORDER_BINS = 4096;
 
 // BY_STEPS: the key is the packet's known number of steps (after a counting pass the lifetimes are
@@ -1025,23 +1072,32 @@ NXC_DEV int steps_bin(const long long *__restrict__ steps, int64_t i, double sca
     return NXC_ORDER_BINS - 1 - (b < 0 ? 0 : b);
 }
 
-NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t n, int64_t i, double scale)
+NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t stride, int64_t i, double scale)
 {
-    const double vx = soa[4 * n + i], vy = soa[5 * n + i], vz = soa[6 * n + i];
+    const double vx = soa[4 * stride + i], vy = soa[5 * stride + i], vz = soa[6 * stride + i];
     const double f = (vx * vx + vy * vy + vz * vz) * scale;
     int b = (f >= 0.0 && f < (double)NXC_ORDER_BINS) ? (int)f : (f >= (double)NXC_ORDER_BINS ? NXC_ORDER_BINS - 1 : 0);
     return NXC_ORDER_BINS - 1 - b;
 }
 
-// Largest finite |v|^2 of the resident packets (bit pattern of a non-negative double: its order
-// as an unsigned integer is its order as a number).
+// The bin scale: given by the host, or (max_bits != null) derived on the device from the largest
+// |v|^2 that k_speed_max left there, so that a piece can be ordered without a host round trip.
+NXC_DEV double order_scale(double scale, const unsigned long long *__restrict__ max_bits)
+{
+    if (!max_bits) return scale;
+    const double m = __longlong_as_double((long long)*max_bits);
+    return m > 0.0 ? (double)(NXC_ORDER_BINS - 1) / m : 0.0;
+}
+
+// Largest finite |v|^2 of the packets (bit pattern of a non-negative double: its order as an
+// unsigned integer is its order as a number).
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_speed_max(const double *__restrict__ soa, int64_t n, unsigned long long *__restrict__ out)
+k_speed_max(const double *__restrict__ soa, int64_t stride, int64_t n, unsigned long long *__restrict__ out)
 {
     double m = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const double vx = soa[4 * n + i], vy = soa[5 * n + i], vz = soa[6 * n + i];
+        const double vx = soa[4 * stride + i], vy = soa[5 * stride + i], vz = soa[6 * stride + i];
         const double f = vx * vx + vy * vy + vz * vz;
         if (f <= 1.7976931348623157e308 && f > m) m = f;
     }
@@ -1054,44 +1110,97 @@ k_speed_max(const double *__restrict__ soa, int64_t n, unsigned long long *__res
         atomicMax(out, (unsigned long long)__double_as_longlong(m));
 }
 
-template <bool BY_STEPS>
+// LDS: privatised bins (the launches that order a whole resident set); !LDS: straight global
+// atomics, for the launches that run BESIDE a persistent kernel whose block leaves no LDS free.
+template <bool BY_STEPS, bool LDS>
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_order_hist(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t n,
-             double scale, unsigned long long *__restrict__ hist)
+k_order_hist(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
+             int64_t n, double scale_, const unsigned long long *__restrict__ max_bits,
+             unsigned long long *__restrict__ hist)
 {
-    __shared__ unsigned lh[NXC_ORDER_BINS];
-    for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x) lh[b] = 0;
-    __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        atomicAdd(&lh[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, n, i, scale)], 1u);
-    __syncthreads();
-    for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
-        if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+    const double scale = order_scale(scale_, max_bits);
+    if (LDS) {
+        __shared__ unsigned lh[NXC_ORDER_BINS];
+        for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x) lh[b] = 0;
+        __syncthreads();
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * blockDim.x)
+            atomicAdd(&lh[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1u);
+        __syncthreads();
+        for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
+            if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * blockDim.x)
+            atomicAdd(&hist[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1ull);
+    }
 }
 
-// The state columns in queue order: out[c][q] = soa[c][order[q]].
+// hist[NXC_ORDER_BINS] -> exclusive running sum in place: the scatter cursors.  One wave, no LDS
+// (it may have to run on a CU whose LDS a persistent kernel owns): lane l sums its 64 bins, the
+// lanes' totals are scanned with shuffles.
+__global__ void __launch_bounds__(64)
+k_order_scan(unsigned long long *__restrict__ hist)
+{
+    constexpr int PER = NXC_ORDER_BINS / 64;
+    const int lane = threadIdx.x;
+    unsigned long long sum = 0;
+    for (int j = 0; j < PER; j++) sum += hist[lane * PER + j];
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    unsigned long long acc = incl - sum;
+    for (int j = 0; j < PER; j++) {
+        const unsigned long long v = hist[lane * PER + j];
+        hist[lane * PER + j] = acc;
+        acc += v;
+    }
+}
+
+// The state columns in queue order: out[c * out_stride + q] = soa[c * stride + order[q] - base],
+// q < n (order holds indices into the whole set: the piece's first packet is number `base`).
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_order_gather(const double *__restrict__ soa, int64_t n, const unsigned *__restrict__ order,
-               double *__restrict__ out)
+k_order_gather(const double *__restrict__ soa, int64_t stride, int64_t n,
+               const unsigned *__restrict__ order, unsigned base, double *__restrict__ out,
+               int64_t out_stride)
 {
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n;
          q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = order[q];
+        const int64_t i = order[q] - base;
 #pragma unroll
-        for (int c = 0; c < 8; c++) out[c * n + q] = soa[c * n + i];
+        for (int c = 0; c < 8; c++) out[c * out_stride + q] = soa[c * stride + i];
     }
 }
 
 template <bool BY_STEPS>
 __global__ void __launch_bounds__(NXC_BLOCK)
-k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t n,
-                double scale, unsigned long long *__restrict__ cursor, unsigned *__restrict__ order)
+k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
+                int64_t n, double scale_, const unsigned long long *__restrict__ max_bits,
+                unsigned long long *__restrict__ cursor, unsigned *__restrict__ order, unsigned base)
 {
+    const double scale = order_scale(scale_, max_bits);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long pos =
-            atomicAdd(&cursor[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, n, i, scale)], 1ull);
-        order[pos] = (unsigned)i;
+            atomicAdd(&cursor[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1ull);
+        order[pos] = base + (unsigned)i;
+    }
+}
+
+// Sum of the per-piece counters of a streamed pass (each piece has its own queue head).
+__global__ void k_sum_counters(const DevCounters *__restrict__ pieces, int n, DevCounters *__restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        DevCounters t{};
+        for (int p = 0; p < n; p++) {
+            t.particle_steps += pieces[p].particle_steps; t.samples += pieces[p].samples;
+            t.samples_binned += pieces[p].samples_binned; t.nonfinite += pieces[p].nonfinite;
+            t.bad_step += pieces[p].bad_step; t.neg_frac += pieces[p].neg_frac;
+            t.unfinished += pieces[p].unfinished;
+        }
+        *out = t;
     }
 }

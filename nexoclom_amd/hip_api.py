@@ -31,7 +31,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_integrate_const_rows', 'nxc_rows_fetch', 'nxc_rows_fetch_f32', 'nxc_device_bus_id',
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
            'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info',
-           'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms')
+           'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms',
+           'nxc_integrate_const_streamed')
 ABI_VERSION = 2
 
 
@@ -484,6 +485,18 @@ class Context:
         self._check(self.lib.nxc_integrate_const_async(
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             C.c_uint32(NXC_RUN_IMAGE if image else 0)))
+
+    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=8):
+        """Upload the (8, N) host array and integrate it in one pipelined pass (the next piece
+        crosses PCIe while the current one is integrated).  Asynchronous: ``synchronize()`` before
+        touching ``soa`` or reading results."""
+        soa = _f64(soa)
+        assert soa.ndim == 2 and soa.shape[0] == 8
+        self._keep = soa                      # the copies read it until the stream is drained
+        self._check(self.lib.nxc_integrate_const_streamed(
+            self._h, C.c_int64(soa.shape[1]), _p(soa), C.c_int32(pieces), C.c_double(step),
+            C.c_int64(n_iter), C.c_double(outeredge), C.c_uint32(NXC_RUN_IMAGE if image else 0)))
+        self.n_packets = soa.shape[1]
 
     def integrate_var(self, resolution, outeredge, max_steps=10**6):
         n = self.n_packets

@@ -99,6 +99,10 @@ class OracleContext:
     def integrate_const_async(self, step, n_iter, outeredge, image=True):
         self.integrate_const(step, n_iter, outeredge, image=image)
 
+    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=8):
+        self.upload_soa(soa)
+        self.integrate_const(step, n_iter, outeredge, image=image)
+
     def comm_unique_id(self):
         self.log.append('comm_unique_id')
         return bytes(range(128))

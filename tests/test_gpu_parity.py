@@ -404,3 +404,37 @@ def test_resident_rows_equal_the_fetched_rows_and_feed_the_image(ctx, narrow):
     store.free()
     with pytest.raises(Exception):
         store.download()
+
+
+def test_streamed_pass_equals_upload_then_integrate(ctx):
+    """nxc_integrate_const_streamed (upload, queue order and integration pipelined over pieces on
+    two compute streams + a copy stream) is the same run as nxc_packets_upload +
+    nxc_integrate_const: the same work and sample counters, the same packet-count image, weights
+    to fp64 summation order -- for one piece, several, more pieces than fit evenly, and pieces
+    of a single packet; and the handle stays usable (a plain pass over the now-resident packets)."""
+    f = H.mercury_forces('Na', 1.3)
+    nsteps, n_iter = O.n_output_steps(20000., 30.)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None)
+    ctx.set_bodies(None)
+    im = H.image_setup(f, 'radiance', dims=(128, 128))
+    for n, pieces in ((200003, 8), (200003, 1), (70001, 3), (9, 32), (5000, 32)):
+        X0 = H.sample_x0(n, 77 + pieces, 20000.)
+        soa = np.ascontiguousarray(X0.T)
+        ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                      im['g_tables'], downcast_f32=True)
+        ctx.upload_soa(soa)
+        ctx.integrate_const(30., n_iter, 25., image=True)
+        want_ctr = ctx.counters()
+        want, want_counts = ctx.image_download()
+        ctx.image_clear()
+        ctx.integrate_const_streamed(soa, 30., n_iter, 25., image=True, pieces=pieces)
+        ctx.synchronize()
+        assert ctx.counters() == want_ctr, (n, pieces)
+        got, got_counts = ctx.image_download()
+        assert np.array_equal(got_counts, want_counts) and want_counts.sum() > 100
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=0)
+        ctx.image_clear()
+        ctx.integrate_const(30., n_iter, 25., image=True)       # the packets are resident now
+        assert ctx.counters() == want_ctr
+        assert np.array_equal(ctx.image_download()[1], want_counts)

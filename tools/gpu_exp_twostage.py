@@ -44,7 +44,20 @@ for rep in range(2):
     X = inputs._catalogue[0].X
     t4 = time.time()
     print(f'   first access to one Output.X ({len(X):.3e} rows): {t4-t3:.3f}s', flush=True)
+    img_host = img.packet_image.copy()
     del inputs, img, X
+for rep in range(2):
+    inputs = Input(infile)
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(1e6, seed=7, context=ctx, sampler='device', generator='pcg64')
+    t1 = time.time()
+    img2 = inputs.produce_image({'quantity': 'radiance', 'dims': '512,512'}, context=ctx)
+    t2 = time.time()
+    print(f"Input.run(1e6, sampler='device', generator='pcg64'): {t1-t0:.3f}s; produce_image "
+          f'{t2-t1:.3f}s; total {t2-t0:.3f}s; same packet counts as the host-sampled run: '
+          f'{bool((img2.packet_image == img_host).all())}', flush=True)
+    del inputs, img2
 inputs = Input(infile)
 prof = cProfile.Profile()
 prof.enable()

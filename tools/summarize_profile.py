@@ -61,6 +61,18 @@ if dom:
         if 'TCC_EA0_ATOMIC_sum' in s:
             traffic['k_const_fused_atomic_requests_per_launch'] = \
                 s['TCC_EA0_ATOMIC_sum']['mean_per_launch']
+        if 'SQ_ACTIVE_INST_VALU' in s and 'GRBM_GUI_ACTIVE' in s:
+            # quad-cycles in which a VALU instruction was issuing, summed over the 1024 SIMDs,
+            # against the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+            traffic['k_const_fused_valu_busy_frac'] = \
+                s['SQ_ACTIVE_INST_VALU']['mean_per_launch']*4/1024 / \
+                (s['GRBM_GUI_ACTIVE']['mean_per_launch']/8)
+        if os.path.exists(bl):
+            try:
+                traffic['particle_steps_per_launch'] = \
+                    json.loads(open(bl).read().strip().splitlines()[-1])['particle_steps_per_pass']
+            except (ValueError, KeyError, IndexError):
+                pass
         json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
 print(json.dumps({'kernels': list(summary), 'traffic': traffic}, indent=1))
 for k, d in summary.items():
