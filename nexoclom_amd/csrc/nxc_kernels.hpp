@@ -348,12 +348,14 @@ struct WaveQueue {
                 if (b >= n) { drained = true; break; }
                 c_cnt = (b + NXC_CHUNK <= n) ? NXC_CHUNK : (int)(n - b);
                 c_pos = 0;
+#ifndef NXC_NO_STREAM_WAIT      /* (A/B builds only: what the wait costs the resident pass) */
                 if (const unsigned long long *avail = L.avail) {      // streamed upload
                     if (!wait_published(avail, (unsigned long long)(b + c_cnt))) {
                         drained = true; stalled = true; c_cnt = 0;
                         break;
                     }
                 }
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane < c_cnt) {
                     const long long src = b + lane;

@@ -101,3 +101,84 @@ def image_setup(f, quantity='radiance', dims=(64, 64), center=(0., 0.), width=(8
     gt = g_tables(species, f.aplanet, f.R_km, wavelengths) if quantity == 'radiance' else []
     return dict(M=M, xrange=xr, zrange=zr, xedges=xedges, zedges=zedges, apix=apix,
                 g_tables=gt, quantity=quantity, dims=list(dims))
+
+
+def collinear_point(GM, gm, a, omega):
+    """L1 of THIS model (planet held fixed at the origin, moon on a prescribed circle: there is
+    no indirect term, so no triangular points either) and the growth rate of its unstable mode.
+    Rotating frame, x along planet -> moon: effective potential
+    U = GM/r + gm/|r - r_m| - omega^2 r^2 / 2  (GM, gm negative as in the C ABI).
+    Equilibrium: |GM|/x^2 - |gm|/(a - x)^2 = omega^2 x.  Linearised: d2(xi)/dt2 - 2 omega
+    d(eta)/dt = A xi, d2(eta)/dt2 + 2 omega d(xi)/dt = B eta with A = omega^2 + 2 K, B = omega^2 -
+    K, K = |GM|/x^3 + |gm|/(a - x)^3;  lambda^4 + (4 omega^2 - A - B) lambda^2 + A B = 0."""
+    M, m = -GM, -gm
+    lo, hi = 0.5*a, a*(1 - 1e-9)
+    f = lambda x: M/x**2 - m/(a - x)**2 - omega**2*x          # noqa: E731
+    for _ in range(200):
+        mid = 0.5*(lo + hi)
+        lo, hi = (mid, hi) if f(mid) > 0 else (lo, mid)
+    x = 0.5*(lo + hi)
+    K = M/x**3 + m/(a - x)**3
+    A, B = omega**2 + 2*K, omega**2 - K
+    b = 4*omega**2 - A - B
+    lam2 = (-b + np.sqrt(b*b - 4*A*B))/2
+    lam = np.sqrt(lam2)
+    # unstable eigenvector (xi, eta): (lam^2 - A) xi = 2 omega lam eta
+    return x, lam, (lam2 - A)/(2*omega*lam)
+
+
+
+def collinear_case():
+    """Five packets around the inner collinear point of a planet + one moon of mass ratio 0.01:
+    one exactly on it with the co-rotating velocity, four displaced along the unstable
+    eigenvector of the linearised rotating-frame equations (two opposite, one doubled, one ten
+    times as far)."""
+    GM, mu, a = -1.0e-6, 0.01, 6.0
+    gm = mu*GM
+    omega = np.sqrt(-GM/a**3)
+    x1, lam, slope = collinear_point(GM, gm, a, omega)
+    assert 0.8*a*(1 - (mu/3)**(1/3)) < x1 < a and 2.0 < lam/omega < 3.5
+    period = 2*np.pi/omega
+    step, n_iter = period/4000, 1334                   # a third of an orbit: lambda t = 6.1
+    T = step*n_iter
+    phi = 0.3                                          # moon's phase at t_remaining = 0
+    theta0 = phi - omega*T                             # ... and at the start
+    ex = np.array([-np.sin(theta0), np.cos(theta0), 0.])        # planet -> moon
+    ey = np.array([-np.cos(theta0), -np.sin(theta0), 0.])       # 90 degrees ahead
+    eps = np.array([0., 1e-7, -1e-7, 2e-7, 1e-6])*a
+    X0 = np.zeros((len(eps), 8))
+    for i, d in enumerate(eps):
+        xi, eta = d, d*slope
+        pos = (x1 + xi)*ex + eta*ey
+        # rotating-frame velocity of the unstable mode (lam xi, lam eta) + co-rotation omega z x r
+        vel = lam*(xi*ex + eta*ey) + omega*np.cross([0., 0., 1.], pos)
+        X0[i] = [T, *pos, *vel, 1.0]
+    return dict(GM=GM, gm=gm, a=a, omega=omega, phi=phi, T=T, step=step, n_iter=n_iter, X0=X0,
+                eps=eps, x1=x1, lam=lam, slope=slope, theta0=theta0, period=period)
+
+
+def check_collinear_run(case, traj):
+    """traj (8, n_iter + 1, 5) of collinear_case(): the packet on the point stays, the displaced
+    ones leave as exp(lambda t) along the unstable direction."""
+    a, lam, slope, eps = case['a'], case['lam'], case['slope'], case['eps']
+    k = np.arange(case['n_iter'] + 1)
+    th = case['theta0'] + case['omega']*case['step']*k
+    ux, uy = np.stack([-np.sin(th), np.cos(th)]), np.stack([-np.cos(th), -np.sin(th)])
+    xi = traj[1]*ux[0][:, None] + traj[2]*ux[1][:, None] - case['x1']
+    eta = traj[1]*uy[0][:, None] + traj[2]*uy[1][:, None]
+    assert np.all(traj[7] == 1.0) and np.all(traj[3] == 0.0)
+    # the packet at the point itself: what is left is the seed of the instability from rounding
+    # and the integrator's error, far below the displaced packets' excursions
+    assert np.abs(xi[:, 0]).max() < 1e-11*a and np.abs(eta[:, 0]).max() < 1e-11*a
+    t = case['step']*k
+    for i in range(1, len(eps)):
+        grow = (xi[:, i] - xi[:, 0])/eps[i]
+        late = t > 0.15*case['period']                 # the decaying companion modes have died
+        rate = np.polyfit(t[late], np.log(grow[late]), 1)[0]
+        assert abs(rate/lam - 1) < 1e-3, (i, rate/lam)
+        np.testing.assert_allclose(grow[-1], np.exp(lam*case['T']), rtol=5e-3)
+        np.testing.assert_allclose((eta[late, i] - eta[late, 0])/(xi[late, i] - xi[late, 0]),
+                                   slope, rtol=2e-3)
+    # opposite displacements run away in opposite directions, twice the displacement twice as far
+    np.testing.assert_allclose(xi[-1, 2] - xi[-1, 0], -(xi[-1, 1] - xi[-1, 0]), rtol=1e-3)
+    np.testing.assert_allclose(xi[-1, 3] - xi[-1, 0], 2*(xi[-1, 1] - xi[-1, 0]), rtol=1e-3)

@@ -77,3 +77,16 @@ def test_single_body_inputs_have_no_bodies_and_variable_step_refuses_them():
     jup.options.step_size = 0.
     with pytest.raises(NotImplementedError):
         Output(jup, 10, seed=1, integrate=False, save=False)
+
+
+def test_collinear_point_dynamics_in_the_c_oracle(coracle):
+    """The physics pin of tests/test_gpu_bodies.py::test_collinear_point_of_the_planet_moon_system
+    on the CPU side: the oracle's moon model too reproduces the closed-form dynamics around the
+    inner collinear point (equilibrium, growth rate and direction of the unstable mode)."""
+    case = H.collinear_case()
+    f = O.Forces(GM=case['GM'], vrplanet=0.0, gravity=True, radpres=False, lifetime=0.0, photo=None)
+    b = O.Bodies(gm=(case['gm'],), radius=(1e-3,), a=(case['a'],), omega=(case['omega'],),
+                 phi=(case['phi'],), t0=case['T'], chx_on=False)
+    c = coracle.integrate_const(f, case['X0'], case['step'], case['n_iter'], 1e6,
+                                nrec=case['n_iter'] + 1, bodies=b)
+    H.check_collinear_run(case, c['traj'])

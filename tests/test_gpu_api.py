@@ -625,3 +625,76 @@ def test_device_pcg64_follows_the_seeded_host_stream(ctx):
         np.testing.assert_allclose(b.X0.x.values, a.X0.x.values, rtol=0, atol=1e-6)   # float32 now
         assert len(a.X) == len(b.X) and np.array_equal(a.X.Index.values, b.X.Index.values)
         np.testing.assert_allclose(b.X.x.values, a.X.x.values, rtol=0, atol=1e-5)
+
+
+def test_los_column_through_a_uniform_shell_is_the_chord_length(ctx):
+    """Physics pin of f-1 (parity unpinned: compute_iteration.py needs astropy / PostgreSQL /
+    MESSENGERuvvs and the reference holds no line-of-sight fixture).  Samples of equal weight
+    distributed uniformly in the shell 1.2 R < r < 3 R have a closed-form answer for every line of
+    sight: a cone of half-angle dphi collects w / Apix(d) from each sample at distance d, Apix =
+    pi (d sin dphi)^2 (compute_iteration.py:194-196), so
+
+        radiance = n w / R_cm^2 * 2 / (1 + cos dphi) * L         n = samples per R^3,
+
+    L = length of the line inside the shell (up to the spacecraft-planet distance if it hits the
+    planet, compute_iteration.py:105-115,185), and the number of samples seen is
+    n * 2 pi (1 - cos dphi) * (d_out^3 - d_in^3) / 3 per crossing.  Checked to Monte-Carlo error
+    through LOSResult for lines that cross the shell once, twice, graze it and miss it."""
+    from nexoclom_amd import LOSResult, SpacecraftData
+    rng = np.random.default_rng(2026)
+    r1, r2, N = 1.2, 3.0, 6_000_000
+    r = np.cbrt(rng.uniform(r1**3, r2**3, N))
+    u = rng.normal(size=(3, N))
+    xyz = (u/np.linalg.norm(u, axis=0)*r).astype(np.float32)
+    density = N/(4/3*np.pi*(r2**3 - r1**3))
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    out = Output.__new__(Output)                       # a stored Output made of these samples
+    out.inputs, out.npackets, out.totalsource = inputs, N, float(N)
+    out.idnum, out.filename = 1, None
+    import pandas as pd
+    from nexoclom_amd.units import Quantity
+    out.X = pd.DataFrame({'Index': np.arange(N, dtype=np.int32), 'x': xyz[0], 'y': xyz[1],
+                          'z': xyz[2], 'vy': np.zeros(N, np.float32),
+                          'frac': np.ones(N, np.float32)})
+    out.X0 = pd.DataFrame({'x': np.zeros(N, np.float32)})
+    out.aplanet, out.vrplanet = Quantity(0.3514, 'au'), Quantity(0.0, 'km/s')
+    out.unit_km = inputs.geometry.planet.radius.value
+    inputs._catalogue.append(out)
+    # spacecraft 8 R sunward of the planet (y = -8: what it sees in front of the planet is lit),
+    # looking along +y at impact parameters b
+    D, dphi = 8.0, np.radians(1.0)
+    b = np.array([0.0, 0.6, 1.1, 1.19, 2.0, 2.7, 3.3])
+    sc = SpacecraftData(b, np.full_like(b, -D), np.zeros_like(b), np.zeros_like(b),
+                        np.ones_like(b), np.zeros_like(b))
+    g = 1.7
+    los = LOSResult(sc, inputs, {'quantity': 'radiance', 'g': str(g)}, dphi=dphi, context=ctx)
+    it = los.compute_iteration(out, sc)
+
+    def crossings(bi):
+        """[(d_in, d_out)] along the line, from the spacecraft."""
+        if bi >= r2:
+            return []
+        far = np.sqrt(r2**2 - bi**2)
+        if bi >= r1:
+            return [(D - far, D + far)]
+        near = np.sqrt(r1**2 - bi**2)
+        front = [(D - far, D - near)]
+        return front if bi < 1.0 else front + [(D + near, D + far)]   # the planet hides the back
+    R_cm = out.unit_km*1e5
+    w = 1.0*g/1e6                                      # frac * g / 1e6 (ModelResult.py:148-161)
+    for k, bi in enumerate(b):
+        segs = crossings(bi)
+        length = sum(d1 - d0 for d0, d1 in segs)
+        want = density*w/R_cm**2 * 2/(1 + np.cos(dphi)) * length
+        count = density*2*np.pi*(1 - np.cos(dphi))*sum(d1**3 - d0**3 for d0, d1 in segs)/3
+        got, seen = it['radiance'].values[k], it['npackets'].values[k]
+        if not segs:
+            assert got == 0 and seen == 0
+            continue
+        # Monte-Carlo error of `seen` samples (the weights w / Apix vary by < 2 along a crossing),
+        # plus the variation of the chord across the cone where the line runs close to an edge
+        sigma = 4/np.sqrt(count) + (0.06 if min(abs(bi - r1), abs(bi - r2), abs(bi - 1.0)) < 0.2
+                                    else 0.0)
+        assert abs(seen/count - 1) < sigma, (bi, seen, count)
+        assert abs(got/want - 1) < sigma, (bi, got, want)
+    assert it['npackets'].values[0] > 2000             # the bound above is a few per cent

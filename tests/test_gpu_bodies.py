@@ -218,3 +218,27 @@ def test_config5_inputfile_end_to_end(ctx, coracle):
     np.testing.assert_allclose(img.image, c['image']*img.atoms_per_packet, rtol=1e-10)
     assert img.packet_image.sum() > 0.5*n
     ctx.set_bodies(None)
+
+
+def test_collinear_point_of_the_planet_moon_system(ctx):
+    """Physics pin of the moons extension (parity unpinned: the reference has no implementation,
+    Output.py:153-155).  One moon of mass ratio 0.01 on a circular orbit: a packet placed AT the
+    model's inner collinear point with the co-rotating velocity stays there (to the integrator's
+    error) for a third of an orbit, while packets displaced along the unstable direction run
+    away as exp(lambda t) with the lambda of the linearised rotating-frame equations.  This ties
+    the direction, magnitude and orbital phase of the moon's pull -- evaluated at the six
+    Dormand-Prince nodes of every step -- to closed-form dynamics; the Jacobi test above only
+    sees their consistency."""
+    case = H.collinear_case()
+    ctx.set_forces(case['GM'], 0.0, gravity=True, radpres=False, lifetime=0.0, photo=None)
+    ctx.set_bounce(None)
+    try:
+        ctx.set_bodies(dict(moons=[dict(gm=case['gm'], radius=1e-3, a=case['a'],
+                                        omega=case['omega'], phi=case['phi'])],
+                            t0=case['T'], chx=None))
+        ctx.upload_packets(case['X0'])
+        traj = ctx.integrate_const(case['step'], case['n_iter'], 1e6,
+                                   nrec=case['n_iter'] + 1)['traj']             # (8, nrec, N)
+    finally:
+        ctx.set_bodies(None)
+    H.check_collinear_run(case, traj)
