@@ -74,6 +74,7 @@ def test_two_ranks_run_the_whole_bench_logic(tmp_path):
     assert line['config']['parallelism'] == 'packet-shard x2'
     assert line['config']['control_plane'] == 'tcp+rccl'
     assert line['value_incl_h2d'] > 0 and line['ms_per_step_incl_h2d'] > 0
+    assert line['h2d_pass'].startswith('pipelined')
     assert line['roofline']['contract_bound'] == 'hbm' and 0 < line['roofline']['frac'] < 1
     assert line['cpu_baseline'] is None and 'with_comm' not in line
     for r in (r0, r1):

@@ -6,7 +6,8 @@
   k_const_fused<ROWS>  a-3/f-3   compact trajectory rows (72 B per live record) -- one chunk and
                        the 13 chunks of Input.run(1e6) in one launch; the dense trajectory
   k_los          f-1       line-of-sight cones ((spectrum, sample) pair tests)
-  k_sample       f-4       initial states on the device (64 B written per packet)
+  k_sample       f-4       initial states on the device (64 B written per packet), Philox and PCG64
+  k_stream_copy            the box's streaming-copy ceiling; k_clock: its clock under fp64 load
   k_speed_max / k_order_hist / k_order_scatter   queue order of the resident packets
   k_const_fused  a-1..a-3  the STRESS vector of SURVEY 8(d): every packet alive for all 1667 steps
 
@@ -167,6 +168,17 @@ def main():
     # last_kernel_ms of sample_packets times k_sample itself (the ordering follows it)
     line('k_sample', ctx.last_kernel_ms(), N, 'packets', 64,
          f'uniform/flat/isotropic source; whole call incl. queue ordering {call_ms:.2f} ms')
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ctx.sample_packets(N, 1234, 0, pcg64=(N, 0), **src)
+        call_ms = (time.perf_counter() - t0)*1e3
+    line('k_sample[pcg64]', ctx.last_kernel_ms(), N, 'packets', 64,
+         f"the same source following NumPy's PCG64 stream of the seed (128-bit jump-ahead per "
+         f'packet); whole call incl. queue ordering {call_ms:.2f} ms')
+    print(json.dumps({'kernel': 'k_stream_copy', 'GBps_read_plus_written': ctx.stream_copy_gbs(),
+                      'clock_mhz_under_fp64_load': ctx.shader_clock_mhz(),
+                      'note': "the box's own streaming ceiling and shader clock (bench.py prints "
+                              'them as roofline.peak_measured / binding_ceilings.clock_mhz)'}))
     soa = ctx.sample_packets(2_000_000, 1234, 0, download=True, **src)
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -174,7 +186,7 @@ def main():
         up_ms = (time.perf_counter() - t0)*1e3
     print(json.dumps({'kernel': 'nxc_packets_upload', 'call_ms': up_ms, 'packets': soa.shape[1],
                       'note': 'H2D of 64 B/packet from pageable memory + k_speed_max + '
-                              'k_order_hist + k_order_scatter'}))
+                              'k_order_hist + k_order_scan + k_order_scatter + k_order_gather'}))
 
     # ---- SURVEY 8(d)'s stress vector: no early deaths, so no refill, no empty lanes, no queue
     # order -- the step loop's own rate.  Packets start at rest 30 R from the planet, outside its

@@ -8,7 +8,8 @@ TAG=${1:-r01}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 $@"
+# --no-h2d-pass: the pipelined upload pass needs two kernels side by side; counter mode serialises them
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --no-h2d-pass --steps 2 --warmup 1 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 grep '"metric"' $OUT/trace.log > $OUT/bench_line.json
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $BENCH > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
