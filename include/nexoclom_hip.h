@@ -328,7 +328,8 @@ int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double
  * put into queue order while piece p is integrated.  Asynchronous like nxc_integrate_const_async
  * (soa0 must stay valid until nxc_synchronize); afterwards the packets are the resident set, the
  * image holds their samples and nxc_counters_get reports the pass.  Same results as
- * nxc_packets_upload + nxc_integrate_const_async (the order of the queue changes no packet). */
+ * nxc_packets_upload + nxc_integrate_const_async (the order of the queue changes no packet).
+ * Not with moons or surface re-emission set (NXC_ERR_STATE: upload first). */
 int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, int32_t pieces,
                                  double step, int64_t n_iter, double outeredge, uint32_t flags);
 

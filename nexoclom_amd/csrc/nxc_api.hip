@@ -540,12 +540,12 @@ FusedJob whole_set(nxc_handle *h)
     return j;
 }
 
-template <bool IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false>
+template <bool IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false, bool STREAMED = false>
 int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
                  double *d_final, long long *d_steps, const FusedJob &job)
 {
     int grid = 1, block = BLOCK_PERSIST, rc;
-    auto kernel = k_const_fused<IMAGE, BOUNCE, FULL, NBODY>;
+    auto kernel = k_const_fused<IMAGE, BOUNCE, FULL, NBODY, 0, STREAMED>;
     if ((rc = prep_kernel(kernel, lds))) return rc;
     if ((rc = persistent_grid(h, kernel, &block, lds, job.n, &grid))) return rc;
     if (job.timed && (rc = begin_timed(h))) return rc;
@@ -563,6 +563,11 @@ int pick_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double 
                double *d_final, long long *d_steps, const FusedJob &job)
 {
 #define NXC_FUSED(...) launch_fused<__VA_ARGS__>(h, tables, lds, n_iter, edge2, d_final, d_steps, job)
+    if (job.avail) {        // streamed upload: the plain force models only (checked by the caller)
+        const bool full_ = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
+        if (full_) return image ? NXC_FUSED(true, false, true, false, true) : NXC_FUSED(false, false, true, false, true);
+        return image ? NXC_FUSED(true, false, false, false, true) : NXC_FUSED(false, false, false, false, true);
+    }
     if (h->have_bodies) {
         if (h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO)
             return image ? NXC_FUSED(true, false, true, true) : NXC_FUSED(false, false, true, true);
@@ -1651,6 +1656,9 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
     const bool image = (flags & NXC_RUN_IMAGE) != 0;
     if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
     if (n >= (int64_t)0xffffffffll) return fail(NXC_ERR_ARG, "too many packets for one resident set");
+    if (h->have_bodies || h->have_bounce)
+        return fail(NXC_ERR_STATE, "the streamed pass covers the plain force models; with moons or "
+                                   "surface re-emission upload first (nxc_packets_upload)");
     if ((int64_t)pieces > n) pieces = (int32_t)n;
     const size_t per_piece = NXC_ORDER_BINS + 8;                    // bins, then the largest |v|^2
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, (size_t)8 * n * 8))) return rc;
@@ -1670,11 +1678,6 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
     const size_t tables = image ? h->all_bytes : h->force_bytes;
     const size_t lds = persist_lds(tables);
     if ((rc = upload_step(h, step))) return rc;
-    if (h->have_bodies) {
-        if (h->have_bounce)
-            return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
-        if ((rc = upload_moon_table(h, step, n_iter))) return rc;
-    }
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     HIPCHK(hipMemsetAsync(d_avail, 0, sizeof(unsigned long long), h->stream));
     // everything queued on the handle's stream so far (image clear, tables, the zeroed word) first

@@ -326,7 +326,9 @@ struct WaveQueue {
 
     // ROWS: the packet's first row and row count (offsets[id], offsets[id + 1] - offsets[id]) are
     // staged with it and returned in row0 / nrow.
-    template <bool ROWS = false>
+    // STREAMED: the queue is still being filled (wait_published above); a template flag, so that
+    // the resident passes' code -- the bench kernel among them -- carries none of it.
+    template <bool ROWS = false, bool STREAMED = false>
     NXC_DEV long long refill(bool need, int stage_off, double (&s)[8], long long *row0 = nullptr,
                              long long *nrow = nullptr)
     {
@@ -348,14 +350,12 @@ struct WaveQueue {
                 if (b >= n) { drained = true; break; }
                 c_cnt = (b + NXC_CHUNK <= n) ? NXC_CHUNK : (int)(n - b);
                 c_pos = 0;
-#ifndef NXC_NO_STREAM_WAIT      /* (A/B builds only: what the wait costs the resident pass) */
-                if (const unsigned long long *avail = L.avail) {      // streamed upload
-                    if (!wait_published(avail, (unsigned long long)(b + c_cnt))) {
+                if (STREAMED) {
+                    if (!wait_published(L.avail, (unsigned long long)(b + c_cnt))) {
                         drained = true; stalled = true; c_cnt = 0;
                         break;
                     }
                 }
-#endif
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane < c_cnt) {
                     const long long src = b + lane;
@@ -399,7 +399,7 @@ struct WaveQueue {
 // ROWS != 0 (never with IMAGE): every live record -- the initial state and the state after each step
 // while frac > 0 -- goes to row offsets[id] + k of rec[total][10] (doubles, or floats for ROWS = 2) with lossfrac accumulated as
 // (lossfrac + frac_before) - frac_after per step (Output.py:420-421) from 0.
-template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, int ROWS = 0>
+template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, int ROWS = 0, bool STREAMED = false>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
@@ -411,8 +411,9 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               const unsigned long long *__restrict__ avail = nullptr)
 {
     static_assert(!(IMAGE && ROWS), "the rows pass has no image");
+    static_assert(!(STREAMED && (ROWS || BOUNCE || NBODY)), "the streamed pass is the plain one");
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, steps_out, &ctr->queue_head, n,
-                          offsets, avail);
+                          offsets, STREAMED ? avail : nullptr);
     const LutView T = lut_view(F.tab);
     ImageRegs IR{};
     if (IMAGE) IR = image_regs(lds_header().G);
@@ -449,9 +450,9 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 #ifdef NXC_REFILL_MIN      /* experiment: hand out packets only once this many lanes are free */
         const unsigned long long free_ = __ballot(!has);
         const bool serve = __popcll(free_) >= NXC_REFILL_MIN || free_ == ~0ull;
-        const long long got = serve ? q.refill<ROWS != 0>(!has, stage_off, s, &row0, &nrow) : -1;
+        const long long got = serve ? q.refill<ROWS != 0, STREAMED>(!has, stage_off, s, &row0, &nrow) : -1;
 #else
-        const long long got = q.refill<ROWS != 0>(!has, stage_off, s, &row0, &nrow);
+        const long long got = q.refill<ROWS != 0, STREAMED>(!has, stage_off, s, &row0, &nrow);
 #endif
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; lossfrac = 0.0; }
         if (__ballot(has) == 0) break;
@@ -560,7 +561,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     }
     flush_counter(&ctr->particle_steps, my_steps);
     if (ROWS) flush_counter(&ctr->unfinished, my_overrun);
-    if (!ROWS && q.stalled && (threadIdx.x & 63) == 0) atomicAdd(&ctr->unfinished, 1ull);
+    if (STREAMED && q.stalled && (threadIdx.x & 63) == 0) atomicAdd(&ctr->unfinished, 1ull);
     if (IMAGE) {
         flush_counter(&ctr->samples, my_samples);
         flush_counter(&ctr->samples_binned, my_binned);
