@@ -17,6 +17,8 @@ import time
 
 from . import input_classes as spec
 
+HOST_SAMPLER_THREADS = 4        # Outputs of one launch group drawn side by side (Input.run)
+
 # section name in the file -> (attribute on the Input, class that interprets it)
 SECTIONS = (('geometry', spec.Geometry), ('surfaceinteraction', spec.SurfaceInteraction),
             ('forces', spec.Forces), ('spatialdist', spec.SpatialDist),
@@ -162,6 +164,20 @@ class Input:
                 # far fewer in practice; the row store spills its oldest runs to the host)
                 group = min(passes - number, self._group_limit(size, context)) if together else 1
                 outs = []
+                if together and sampler == 'numpy' and group > 1:
+                    # the Outputs of a group are independent draws (seed + k): sample them on a
+                    # few threads (NumPy releases the GIL in its loops), integrate them together
+                    from concurrent.futures import ThreadPoolExecutor
+                    seeds = [None if seed is None else seed + made + g for g in range(group)]
+                    with ThreadPoolExecutor(max_workers=min(group, HOST_SAMPLER_THREADS)) as pool:
+                        outs = list(pool.map(
+                            lambda s_: Output(self, size, compress=compress, device=device,
+                                              keep_trajectory=keep_trajectory, context=context,
+                                              integrate=False, save=False, seed=s_), seeds))
+                    number += group
+                    drawn += size*group
+                    made += group
+                    group = 0
                 for g in range(group):
                     number += 1
                     print(f'Starting iteration #{number} of {passes}')

@@ -180,6 +180,8 @@ class ModelImage(ModelResult):
         runs = list(self.inputs._catalogue)
         if not runs:
             print('No model outputs found for these inputs.')
+        if self._from_resident(runs):
+            return
         for run in runs:
             print(f'Output filename: {run.filename}')
             weighted, counted = self.create_image(run)
@@ -187,6 +189,37 @@ class ModelImage(ModelResult):
             self.packet_image += counted.histogram
             self.totalsource += run.totalsource
             self.xaxis, self.zaxis = weighted.x, weighted.y
+
+    def _from_resident(self, runs):
+        """The same sum when every run's rows are still in HBM and the runs share their geometry
+        (one Input.run): the image pair stays on the device across the runs -- it IS the running
+        sum of ModelImage.py:96-98 -- and comes to the host once.  False: not applicable."""
+        from .Output import Output
+        if not runs or not all(isinstance(run, Output) for run in runs):
+            return False
+        ctx = self.context()
+        views = [run.resident_rows(ctx) for run in runs]
+        same = {(float(run.aplanet), float(run.vrplanet)) for run in runs}
+        if any(v is None for v in views) or len(same) != 1:
+            return False
+        (aplanet, vrplanet_kms), = same
+        self._set_image(ctx, aplanet, vrplanet_kms/self.unit_km, downcast=False)    # clears it
+        totals = {}
+        for run, (store, first, count, _) in zip(runs, views):
+            print(f'Output filename: {run.filename}')
+            if count:
+                ctx.image_accumulate_rows(store, first, count)
+                for key, v in ctx.counters().items():
+                    totals[key] = totals.get(key, 0) + v
+            self.totalsource += run.totalsource
+        self.counters = totals
+        assert totals.get('nonfinite', 0) == 0, 'Non-finite weights'
+        image, counts = ctx.image_download()
+        self.image += image
+        self.packet_image += counts.astype(float)
+        h = Histogram2dResult(image, self.xedges, self.zedges)
+        self.xaxis, self.zaxis = h.x, h.y
+        return True
 
     def finalize(self):
         """Scale to a source rate of 1e23 atoms/s (ModelImage.py:102-105); deferred by the

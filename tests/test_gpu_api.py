@@ -698,3 +698,31 @@ def test_los_column_through_a_uniform_shell_is_the_chord_length(ctx):
         assert abs(seen/count - 1) < sigma, (bi, seen, count)
         assert abs(got/want - 1) < sigma, (bi, got, want)
     assert it['npackets'].values[0] > 2000             # the bound above is a few per cent
+
+
+def test_row_stores_spill_to_the_host_when_hbm_is_needed(ctx):
+    """The catalogue's rows stay in HBM only while there is room: before a new store is built
+    the oldest are spilled to their Outputs' host memory (Context.make_room), and the Outputs --
+    frames, images, line-of-sight runs -- keep working from the host copy."""
+    inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+    inputs.options.endtime = type(inputs.options.endtime)(6000., 's')
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(3000, packs_per_it=1000, seed=4, context=ctx)
+    outs = inputs._catalogue
+    assert all(o.resident_rows(ctx) is not None and o._X is None for o in outs)
+    store = outs[0]._store
+    assert all(o._store is store for o in outs) and store.total == sum(o._nrows for o in outs)
+    params = {'quantity': 'column', 'dims': '64,64'}
+    before = inputs.produce_image(params, context=ctx)
+    free, total = ctx.mem_info()
+    ctx.make_room(total)                       # more than can ever be free: everything spills
+    assert store._r is None and all(o.resident_rows(ctx) is None for o in outs)
+    assert all(o._X is not None and len(o.X) == o._nrows for o in outs)     # rows are on the host now
+    after = inputs.produce_image(params, context=ctx)
+    assert np.array_equal(before.packet_image, after.packet_image) and before.packet_image.sum() > 100
+    np.testing.assert_allclose(after.image, before.image, rtol=1e-12, atol=0)
+    assert ctx.mem_info()[0] >= free           # the store's memory came back
+    # and the next run builds a new store as if nothing had happened
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(4000, packs_per_it=1000, seed=4, context=ctx)
+    assert len(inputs._catalogue) == 4 and inputs._catalogue[-1].resident_rows(ctx) is not None

@@ -1,5 +1,8 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python tools/gpu_exp_variants.py nexoclom_amd/lib/libnexoclom_hip.so build/exp/liblut1.so build/exp/libold7bf.so nexoclom_amd/lib/libnexoclom_hip.so build/exp/liblut1.so build/exp/libold7bf.so nexoclom_amd/lib/libnexoclom_hip.so build/exp/liblut1.so build/exp/libold7bf.so > gpurun_out/r3_variants5.log 2>&1
-cat gpurun_out/r3_variants5.log
+timeout -k 10 600 python -m pytest tests/test_gpu_api.py -x -q -m gpu > gpurun_out/r3_t15.log 2>&1
+echo "exit $?" >> gpurun_out/r3_t15.log
+tail -5 gpurun_out/r3_t15.log
+timeout -k 10 300 python tools/gpu_exp_twostage.py > gpurun_out/r3_twostage4.log 2>&1
+grep "Input.run" gpurun_out/r3_twostage4.log | cut -c1-200
