@@ -590,10 +590,19 @@ class Output:
 
     def _write(self, filename):
         data = {f'X0.{c}': self.X0[c].values for c in self.X0}
-        if self._X is None and self._store is not None:
+        store = self._store
+        if self._X is None and store is not None and store._r is not None:
             # straight from HBM (own copy stream; possibly on the writer thread): the frame itself
-            # is not built for a file
-            rows, idx = self._host_rows()
+            # is not built for a file.  (If the store is spilled meanwhile, the frame exists.)
+            try:
+                rows, idx = self._host_rows()
+            except Exception:
+                if self._X is None:
+                    raise
+                rows = None
+        else:
+            rows = None
+        if rows is not None:
             data['X.Index'] = idx
             data.update({f'X.{c}': rows[k] for k, c in enumerate(STATE_COLS)})
             data['X.lossfrac'] = rows[8]

@@ -5,6 +5,7 @@ entry point raises.  Arrays cross the boundary as C-contiguous float64 NumPy buf
 """
 import ctypes as C
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -158,6 +159,7 @@ class RowStore:
     def __init__(self, ctx, handle):
         self.ctx, self._r = ctx, handle
         self.owners = weakref.WeakSet()       # the Outputs whose rows these are
+        self._lock = threading.RLock()        # a file writer may be reading while the store is spilled
         total, f32 = C.c_int64(0), C.c_int32(0)
         ctx._check(ctx.lib.nxc_rows_info(handle, C.byref(total), C.byref(f32)))
         self.total, self.narrow = int(total.value), bool(f32.value)
@@ -171,17 +173,19 @@ class RowStore:
         count = self.total - first if count is None else int(count)
         rows = np.empty((9, count), dtype=np.float32 if self.narrow else np.float64)
         idx = np.empty(count, dtype=np.int32 if self.narrow else np.int64) if index else None
-        if self._r is None:
-            raise HipError('the row store has been freed')
-        self.ctx._check(self.ctx.lib.nxc_rows_download(
-            self.ctx._h, self._r, C.c_int64(first), C.c_int64(count),
-            rows.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p) if index else None))
+        with self._lock:
+            if self._r is None:
+                raise HipError('the row store has been freed')
+            self.ctx._check(self.ctx.lib.nxc_rows_download(
+                self.ctx._h, self._r, C.c_int64(first), C.c_int64(count),
+                rows.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p) if index else None))
         return rows, idx
 
     def free(self):
-        if self._r is not None and getattr(self.ctx, '_h', None):
-            self.ctx.lib.nxc_rows_free(self.ctx._h, self._r)
-        self._r = None
+        with self._lock:
+            if self._r is not None and getattr(self.ctx, '_h', None):
+                self.ctx.lib.nxc_rows_free(self.ctx._h, self._r)
+            self._r = None
 
     def spill(self):
         """Leave HBM: every owner first takes its rows to the host."""

@@ -438,3 +438,39 @@ def test_streamed_pass_equals_upload_then_integrate(ctx):
         ctx.integrate_const(30., n_iter, 25., image=True)       # the packets are resident now
         assert ctx.counters() == want_ctr
         assert np.array_equal(ctx.image_download()[1], want_counts)
+
+
+def test_rows_of_runs_without_live_records_and_of_a_single_packet(ctx):
+    """Edge cases of the rows protocol: packets that all start dead (no row at all: an empty store
+    that can still be downloaded, binned and freed), and a single packet (one lane of one wave;
+    the launch is sized to the packets, not to the chip)."""
+    f = H.mercury_forces('Na', 1.3)
+    nsteps, n_iter = O.n_output_steps(3000., 30.)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None)
+    ctx.set_bodies(None)
+    im = H.image_setup(f, 'column', dims=(32, 32))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'column', im['xedges'], im['zedges'], [])
+    dead = H.sample_x0(300, 3, 3000.)
+    dead[:, 7] = 0.0
+    ctx.upload_packets(dead)
+    for narrow in (False, True):
+        res = ctx.integrate_const_rows(30., n_iter, 25., narrow=narrow, resident=True)
+        assert res['lengths'].sum() == 0 and res['store'].total == 0
+        rows, index = res['store'].download()
+        assert rows.shape == (9, 0) and index.shape == (0,)
+        ctx.image_accumulate_rows(res['store'])
+        assert ctx.image_download()[1].sum() == 0
+        res['store'].free()
+        assert ctx.integrate_const_rows(30., n_iter, 25., narrow=narrow)['rows'].shape == (9, 0)
+    dense = ctx.integrate_const(30., n_iter, 25., nrec=nsteps)['traj']
+    assert np.array_equal(dense[:, 0, :], dead.T) and not dense[:, 1:, :].any()
+    one = H.sample_x0(1, 5, 3000.)
+    ctx.upload_packets(one)
+    res = ctx.integrate_const_rows(30., n_iter, 25., resident=True)
+    rows, index = res['store'].download()
+    dense = ctx.integrate_const(30., n_iter, 25., nrec=nsteps)['traj']
+    live = dense[7, :, 0] > 0
+    assert res['lengths'][0] == live.sum() == rows.shape[1] >= 1 and not index.any()
+    for c in range(8):
+        assert np.array_equal(rows[c], dense[c, live, 0])
