@@ -60,6 +60,7 @@ extern __shared__ __align__(32) unsigned char nxc_lds[];
 // the nxc_lds symbol instead makes the compiler add its (zero) address to every computed offset,
 // one wasted VALU instruction per table read.
 #define NXC_LDS_AS __attribute__((address_space(3)))
+#define NXC_GLOBAL_AS __attribute__((address_space(1)))
 typedef double nxc_v2d __attribute__((ext_vector_type(2)));
 
 NXC_DEV double lds_f64(int byte_off)

@@ -318,10 +318,19 @@ struct WaveQueue {
     int c_pos = 0, c_cnt = 0;
     bool drained = false, stalled = false;
 
+    // The head pointer comes out of the LDS header as a generic pointer; as such the returning
+    // atomic would be a FLAT instruction, which counts in lgkmcnt as well -- and the step loop's
+    // next wait for an LDS read would then wait out the atomic's trip to memory.
+    static NXC_DEV long long claim(unsigned long long *head)
+    {
+        return (long long)__hip_atomic_fetch_add((NXC_GLOBAL_AS unsigned long long *)head,
+                                                 (unsigned long long)NXC_CHUNK, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     NXC_DEV void start()
     {
-        if ((threadIdx.x & 63) == 0)
-            pending = (long long)atomicAdd(lds_header().L.head, (unsigned long long)NXC_CHUNK);
+        if ((threadIdx.x & 63) == 0) pending = claim(lds_header().L.head);
     }
 
     // ROWS: the packet's first row and row count (offsets[id], offsets[id + 1] - offsets[id]) are
@@ -338,7 +347,7 @@ struct WaveQueue {
         const int want = __popcll(mask);
         const int lane = threadIdx.x & 63;
         const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-        double *stage = reinterpret_cast<double *>(nxc_lds + stage_off);
+        NXC_LDS_AS double *stage = (NXC_LDS_AS double *)(unsigned)stage_off;   // the block starts at LDS address 0
         int served = 0;
         while (served < want) {
             if (c_pos >= c_cnt) {
@@ -358,19 +367,31 @@ struct WaveQueue {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if (lane < c_cnt) {
-                    const long long src = b + lane;
+                    // All nine loads are issued before the first LDS store, through pointers in
+                    // the GLOBAL address space: as generic pointers (they come out of the LDS
+                    // header) the compiler must assume that they may alias the staging block and
+                    // emits load, wait, store, load, wait, store ... -- nine memory round trips in
+                    // a row for every chunk (round 3: seen in the ISA, 3 % of a wave's time).
+                    const NXC_GLOBAL_AS double *g = (const NXC_GLOBAL_AS double *)soa0 + (b + lane);
+                    const NXC_GLOBAL_AS unsigned *gid = (const NXC_GLOBAL_AS unsigned *)ids;
+                    double col[8];
 #pragma unroll
-                    for (int c = 0; c < 8; c++) stage[c * NXC_CHUNK + lane] = soa0[c * n + src];
-                    const long long pid = ids ? (long long)ids[src] : src;
+                    for (int c = 0; c < 8; c++) col[c] = g[c * n];
+                    const long long pid = gid ? (long long)gid[b + lane] : b + lane;
+                    long long o0 = 0, o1 = 0;
+                    if (ROWS) {
+                        const NXC_GLOBAL_AS long long *offs = (const NXC_GLOBAL_AS long long *)L.offsets;
+                        o0 = offs[pid]; o1 = offs[pid + 1];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; c++) stage[c * NXC_CHUNK + lane] = col[c];
                     stage[8 * NXC_CHUNK + lane] = __longlong_as_double(pid);
                     if (ROWS) {
-                        const long long *__restrict__ offs = L.offsets;
-                        const long long o0 = offs[pid], o1 = offs[pid + 1];
                         stage[9 * NXC_CHUNK + lane] = __longlong_as_double(o0);
                         stage[10 * NXC_CHUNK + lane] = __longlong_as_double(o1 - o0);
                     }
                 }
-                if (lane == 0) pending = (long long)atomicAdd(L.head, (unsigned long long)NXC_CHUNK);
+                if (lane == 0) pending = claim(L.head);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -509,12 +530,12 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             if (!live || k >= n_it) {
                 if (want_out) {
                     const LoopK &L = lds_header().L;
-                    if (double *fo = L.final_out) {
+                    if (NXC_GLOBAL_AS double *fo = (NXC_GLOBAL_AS double *)L.final_out) {
                         const long long np = L.n;
 #pragma unroll
                         for (int c = 0; c < 8; c++) fo[c * np + id] = s[c];
                     }
-                    if (long long *so = L.steps_out) so[id] = k;
+                    if (NXC_GLOBAL_AS long long *so = (NXC_GLOBAL_AS long long *)L.steps_out) so[id] = k;
                 }
                 has = false;
             }

@@ -1,7 +1,8 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/r3_bench_2rank.out 2> gpurun_out/r3_bench_2rank.err
-echo "exit code $?" | tee -a gpurun_out/r3_bench_2rank.out
-cat gpurun_out/r3_bench_2rank.out | cut -c1-600
-grep "bench rank" gpurun_out/r3_bench_2rank.err | head
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -x -q -m gpu > gpurun_out/r3_t17.log 2>&1
+echo "exit $?" >> gpurun_out/r3_t17.log
+tail -4 gpurun_out/r3_t17.log
+grep -q "exit 0" gpurun_out/r3_t17.log && timeout -k 10 900 python tools/gpu_exp_variants.py nexoclom_amd/lib/libnexoclom_hip.so build/exp/libold7bf.so nexoclom_amd/lib/libnexoclom_hip.so build/exp/libold7bf.so nexoclom_amd/lib/libnexoclom_hip.so build/exp/libold7bf.so > gpurun_out/r3_variants6.log 2>&1
+cat gpurun_out/r3_variants6.log
