@@ -275,3 +275,58 @@ def test_pathological_states_follow_the_oracle_bit_for_bit(ctx, coracle):
     with np.errstate(all='ignore'):
         r_c, d_c = coracle.rk5(f, X0, hh, want_delta=True)
     assert np.array_equal(r_g, r_c, equal_nan=True) and np.array_equal(d_g, d_c, equal_nan=True)
+
+
+def test_input_run_rows_at_full_size_against_the_c_oracle(ctx, coracle):
+    """The reference's default user flow at the size of BASELINE configs[1]: Input.run(1e6) --
+    13 Outputs of 80 467 packets (Input.py:216-222), integrated in ONE launch, 1.34e8 rows left in
+    HBM.  Against the C oracle: every packet's number of live rows (= its step count, + 1 while
+    it is alive), the total, and -- for 3000 packets picked across all Outputs -- every row of the
+    float32 frame, bit for bit (the oracle's dense trajectory narrowed like save() does,
+    Output.py:528-543), lossfrac and Index included."""
+    if coracle.max_threads() < 16:
+        pytest.skip('needs the GPU box\'s host cores to finish in seconds')
+    import contextlib
+    import io
+    import os
+    import nexoclom_amd
+    from nexoclom_amd import Input
+    inputs = Input(os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles',
+                                'Na.mercury.bench.input'))
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(1e6, seed=99, context=ctx)
+    outs = inputs._catalogue
+    assert len(outs) == 13 and all(len(o) == 80467 for o in outs)
+    assert all(o._store is outs[0]._store for o in outs)             # one launch, one store
+    f = H.mercury_forces('Na', 1.3)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    rng = np.random.default_rng(0)
+    total = 0
+    for k, out in enumerate(outs):
+        # (X0 is stored narrowed like the reference's; the integration used the 64-bit draws)
+        with contextlib.redirect_stdout(io.StringIO()):
+            again = nexoclom_amd.Output(inputs, 80467, seed=99 + k, integrate=False, save=False)
+        X0 = np.ascontiguousarray(again.x0_soa().T)
+        assert np.array_equal(X0.astype(np.float32)[:, 1], out.X0.x.values)
+        c = coracle.integrate_const(f, X0, 30., n_iter, 25., threads=coracle.max_threads())
+        lengths = c['steps'] + (c['final'][:, 7] > 0)
+        assert np.array_equal(out._lengths, lengths), k
+        total += int(lengths.sum())
+        pick = np.sort(rng.choice(80467, 230, replace=False))
+        dense = coracle.integrate_const(f, X0[pick], 30., n_iter, 25., nrec=nsteps)['traj']
+        frame = out.X                                            # downloaded and framed here
+        starts = np.cumsum(lengths) - lengths
+        for j, i in enumerate(pick):
+            rows = frame.iloc[starts[i]:starts[i] + lengths[i]]
+            live = dense[7, :, j] > 0
+            assert live.sum() == lengths[i] and np.all(rows.Index.values == i)
+            for col, name in enumerate(['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac']):
+                assert np.array_equal(rows[name].values, dense[col, live, j].astype(np.float32)), name
+            frac = dense[7, :, j]
+            lossfrac = np.zeros(nsteps)
+            for ct in range(1, int(lengths[i]) + 1 if lengths[i] < nsteps else nsteps):
+                lossfrac[ct] = (lossfrac[ct-1] + frac[ct-1]) - frac[ct]
+            assert np.array_equal(rows.lossfrac.values, lossfrac[live].astype(np.float32))
+            assert np.array_equal(rows.index.values, i*nsteps + np.nonzero(live)[0])
+        out._X = None                                            # keep the host footprint small
+    assert total == outs[0]._store.total and total > 1.2e8

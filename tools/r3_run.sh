@@ -1,5 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/profile_variant.sh r03lut_product nexoclom_amd/lib/libnexoclom_hip.so
-bash tools/profile_variant.sh r03lut_3stage build/exp/liblut3.so
+timeout -k 10 600 python -m pytest tests/test_gpu_edge_fullsize.py -x -q -m gpu -k "input_run_rows" > gpurun_out/r3_t18.log 2>&1
+echo "exit $?" >> gpurun_out/r3_t18.log
+tail -25 gpurun_out/r3_t18.log
