@@ -1,6 +1,5 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_edge_fullsize.py -x -q -m gpu -k "input_run_rows" > gpurun_out/r3_t18.log 2>&1
-echo "exit $?" >> gpurun_out/r3_t18.log
-tail -25 gpurun_out/r3_t18.log
+timeout -k 10 600 python tools/gpu_exp_run1e7.py 1e7 > gpurun_out/r3_run1e7.log 2>&1
+tail -5 gpurun_out/r3_run1e7.log | cut -c1-900
