@@ -801,6 +801,15 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     K.n_lines = d->n_lines;
     K.n_ladder = (int)d->n_ladder;
     K.index_shift = index_shift;
+    K.tan_dphi = std::tan(d->dphi);
+    // block culling measures distances along the boresights: they must be unit vectors (the
+    // reference's are); anything else switches the culling off, never the exact pair test
+    K.cull = (d->dphi > 0 && d->dphi < 1.5 && std::isfinite(K.tan_dphi)) ? 1 : 0;
+    for (int64_t i = 0; i < S && K.cull; i++) {
+        const double b2 = sc[3 * S + i] * sc[3 * S + i] + sc[4 * S + i] * sc[4 * S + i] +
+                          sc[5 * S + i] * sc[5 * S + i];
+        if (!(std::fabs(b2 - 1.0) <= 1e-9)) K.cull = 0;
+    }
     for (int l = 0; l < d->n_lines; l++) {
         PackedLut lut;
         int rc = pack_lut(d->line_v[l], d->line_g[l], d->line_n[l], lut, "g-value table");
@@ -810,7 +819,9 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     }
     const size_t stage_bytes = blob.size();
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
-    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double);
+    // ... | per-wave candidate queues
+    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double) +
+                       (size_t)(NXC_BLOCK / 64) * NXC_LOSQ_BYTES;
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
     // device scratch: blob | sc | ladder | radiance | npackets | included | used
@@ -836,7 +847,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     if (P > 0) {
         if ((rc = prep_kernel(k_los<T, I>, lds))) return rc;
         const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
-        int gx = flat_grid(h, P, NXC_BLOCK);
+        int gx = flat_grid(h, (P + NXC_LOS_BLOCK - 1) / NXC_LOS_BLOCK, NXC_BLOCK);
         if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL((k_los<T, I>), dim3(gx, tiles), dim3(NXC_BLOCK), lds, st, K, base + o_blob,

@@ -788,6 +788,8 @@ __global__ void k_math(const unsigned char *__restrict__ blob, int which, int64_
 struct LosK {
     double sin_dphi, sin_2dphi, cos_thr, cos_thr2_lo, vrplanet, unit_cm2;
     double log1p_s_inv, t0;        // ladder: t_k = t0 (1 + sin_dphi)^k; only to seed the ball search
+    double tan_dphi;               // block culling: a cone's radius per unit distance along its axis
+    int cull, pad_;                // 1: every boresight is a unit vector (checked on the host)
     int n_lines, n_ladder;
     int64_t index_shift;           // subtracted from the index column: packet number inside its Output
     int64_t tile_off;              // byte offset of the spectra tile inside the LDS block
@@ -795,9 +797,128 @@ struct LosK {
 };
 
 constexpr int NXC_LOS_TILE = 128;  // spectra per workgroup tile (8 doubles each)
+#ifndef NXC_LOS_BLOCK_N             // (overridable: tools/ experiments)
+#define NXC_LOS_BLOCK_N 8
+#endif
+constexpr int NXC_LOS_BLOCK = NXC_LOS_BLOCK_N;   // consecutive stored samples tested together first
+
+// One (stored sample, spectrum) pair, exactly as the reference decides and weighs it
+// (compute_iteration.py:177-213).  sp: the spectrum's eight tile values.
+template <typename T, typename I>
+NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spectrum, int64_t p,
+                      double px, double py, double pz, const T *__restrict__ vy,
+                      const T *__restrict__ frac, const I *__restrict__ index,
+                      const double *__restrict__ ladder, double *__restrict__ radiance,
+                      unsigned long long *__restrict__ npackets,
+                      unsigned char *__restrict__ included, long long used_cap,
+                      long long *__restrict__ used_pairs, unsigned long long *__restrict__ n_used,
+                      double rs_1e6, unsigned long long &my_pairs, unsigned long long &my_nonfinite)
+{
+    const double xs = sp[0], ys = sp[1], zs = sp[2], bx = sp[3], by = sp[4], bz = sp[5];
+    const double rx = px - xs, ry = py - ys, rz = pz - zs;
+    const double q = (rx * bx + ry * by) + rz * bz;                // losrad   :178
+    if (!(q > 0.0) || !(q < sp[6])) return;                        // cone in front; planet cut :185
+    const double d2 = (rx * rx + ry * ry) + rz * rz;
+    if (!(q * q >= K.cos_thr2_lo * d2)) return;                    // coarse cone test
+    const double dist = nxc_sqrt(d2);                              // :177
+    double cosang = nxc_div(q, dist);                              // :179
+    cosang = cosang > 1.0 ? 1.0 : cosang;                          // :180
+    if (!(cosang >= K.cos_thr)) return;                            // ang <= dphi  :181-185
+    // KD-tree pre-selection (:164-173): inside any ball |X - (x_sc + bore t_k)| <= t_k sin(2 dphi)
+    const int nk = (int)sp[7];
+    int kc = (int)(nxc_log(q / K.t0) * K.log1p_s_inv);
+    kc = kc < 0 ? 0 : kc;
+    bool cand = false;
+    for (int k = kc - 3; k <= kc + 3; k++) {
+        if (k < 0 || k >= nk) continue;
+        const double t = ladder[k];
+        const double cx = xs + bx * t, cy = ys + by * t, cz = zs + bz * t;
+        const double ex = cx - px, ey = cy - py, ez = cz - pz;
+        const double r = t * K.sin_2dphi;
+        cand = cand || (((ex * ex + ey * ey) + ez * ez) <= r * r);
+    }
+    if (!cand) return;
+    // the weight of the sample (ModelResult.py:150-161, out_of_shadow = 1); pairs that get here
+    // are one in 1e4 of those tested, so it is formed per pair rather than kept per sample
+    const double radvel = (double)vy[p] + K.vrplanet;
+    double gg = K.n_lines > 0 ? lut_interp(lut_view(K.line[0]), radvel) : 0.0;
+#pragma unroll
+    for (int l = 1; l < 4; l++)
+        if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
+    const double weight = nxc_div_const((double)frac[p] * gg, 1e6, rs_1e6);   // 1e6 is mid-range
+    if (!(__builtin_fabs(weight) <= 1.7976931348623157e308) || radvel != radvel) my_nonfinite++;
+    const double ds = dist * K.sin_dphi;
+    const double apix = (3.141592653589793 * (ds * ds)) * K.unit_cm2;         // :194-195
+    double wtemp = nxc_div(weight, apix);
+    const double hx = xs + bx * q, hy = ys + by * q, hz = zs + bz * q;          // :202-206
+    const bool lit = ((hx * hx + hz * hz) > 0x1.0000000000001p+0) || (hy < 0.0);
+    wtemp = lit ? wtemp : wtemp * 0.0;
+    if (wtemp != 0.0) unsafeAtomicAdd(&radiance[spectrum], wtemp);
+    atomicAdd(&npackets[spectrum], 1ull);
+    my_pairs++;
+    if (included) included[index ? (long long)index[p] - K.index_shift : p] = 1;
+    if (used_pairs && wtemp > 0.0) {
+        const unsigned long long slot = atomicAdd(n_used, 1ull);
+        if ((long long)slot < used_cap) {
+            used_pairs[slot] = spectrum;
+            used_pairs[used_cap + slot] = p;
+        }
+    }
+}
+
+// Per-wave queue of (block, spectrum) candidates between the sphere test and the pair tests: a
+// ring in LDS, filled in lane order (ballot + prefix rank), emptied 64 at a time, so that the pair
+// tests run with full waves although only a few per cent of the sphere tests pass.  All calls are
+// wave-uniform.
+constexpr int NXC_LOSQ_SLOTS = 256;
+constexpr int NXC_LOSQ_BYTES = NXC_LOSQ_SLOTS * (8 + 4);
+struct LosQueue {
+    int head = 0, tail = 0;
+    NXC_DEV void push(bool has, long long blk, int j, int qoff)
+    {
+        const unsigned long long m = __ballot(has);
+        if (m == 0) return;
+        if (has) {
+            const int lane = threadIdx.x & 63;
+            const int slot = (tail + __popcll(m & ((1ull << lane) - 1ull))) & (NXC_LOSQ_SLOTS - 1);
+            *reinterpret_cast<long long *>(nxc_lds + qoff + 8 * slot) = blk;
+            *reinterpret_cast<int *>(nxc_lds + qoff + 8 * NXC_LOSQ_SLOTS + 4 * slot) = j;
+        }
+        tail += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    NXC_DEV int waiting() const { return tail - head; }
+    NXC_DEV bool pop(int qoff, long long &blk, int &j)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = waiting() < 64 ? waiting() : 64;
+        const int lane = threadIdx.x & 63;
+        const bool mine = lane < n;
+        if (mine) {
+            const int slot = (head + lane) & (NXC_LOSQ_SLOTS - 1);
+            blk = *reinterpret_cast<const long long *>(nxc_lds + qoff + 8 * slot);
+            j = *reinterpret_cast<const int *>(nxc_lds + qoff + 8 * NXC_LOSQ_SLOTS + 4 * slot);
+        }
+        head += n;
+        __builtin_amdgcn_wave_barrier();
+        return mine;
+    }
+};
 
 // T: double, or float for samples as Output.save() stores them (widened exactly, like restore());
-// I: the type of the packet-index column (int64, or int32 as save() stores it)
+// I: the type of the packet-index column (int64, or int32 as save() stores it).
+//
+// A thread owns BLOCKS of NXC_LOS_BLOCK consecutive stored samples.  The rows of an Output are
+// packet-major (Output.py:435-449), so a block is a short piece of one packet's trajectory: a few
+// steps long, a small sphere.  The block's bounding sphere (centre c, radius R) is tested against
+// every cone of the tile first: a sample can only lie in the cone of half-angle dphi around the
+// line a + t b (|b| = 1) if the centre's distance from that line is at most
+// R + (q_c + R) tan dphi, q_c = (c - a).b, and q_c + R > 0, q_c - R < cut-off (the distance to a
+// line and q are 1-Lipschitz).  The (block, spectrum) candidates that pass -- a few per cent --
+// go through a per-wave LDS queue, so that their samples meet los_pair with full waves;
+// everything else costs one sphere test per 8 pairs.  K.cull = 0 (boresights that are not unit
+// vectors) sends every block through.
 template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
@@ -820,67 +941,70 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     __syncthreads();
     const double rs_1e6 = nxc_recip_seed(1e6);
     unsigned long long my_pairs = 0, my_nonfinite = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
-         p += (int64_t)gridDim.x * blockDim.x) {
-        const double px = x[p], py = y[p], pz = z[p];
-        bool have_w = false;
-        double weight = 0.0;
-        for (int j = 0; j < ns; j++) {
-            const double xs = tile[j * 8 + 0], ys = tile[j * 8 + 1], zs = tile[j * 8 + 2];
-            const double bx = tile[j * 8 + 3], by = tile[j * 8 + 4], bz = tile[j * 8 + 5];
-            const double rx = px - xs, ry = py - ys, rz = pz - zs;
-            const double q = (rx * bx + ry * by) + rz * bz;           // losrad   :178
-            if (!(q > 0.0) || !(q < tile[j * 8 + 6])) continue;        // cone in front; planet cut :185
-            const double d2 = (rx * rx + ry * ry) + rz * rz;
-            if (!(q * q >= K.cos_thr2_lo * d2)) continue;              // coarse cone test
-            const double dist = nxc_sqrt(d2);                          // :177
-            double cosang = nxc_div(q, dist);                          // :179
-            cosang = cosang > 1.0 ? 1.0 : cosang;                      // :180
-            if (!(cosang >= K.cos_thr)) continue;                      // ang <= dphi  :181-185
-            // KD-tree pre-selection (:164-173): inside any ball |X - (x_sc + bore t_k)| <= t_k sin(2 dphi)
-            const int nk = (int)tile[j * 8 + 7];
-            int kc = (int)(nxc_log(q / K.t0) * K.log1p_s_inv);
-            kc = kc < 0 ? 0 : kc;
-            bool cand = false;
-            for (int k = kc - 3; k <= kc + 3; k++) {
-                if (k < 0 || k >= nk) continue;
-                const double t = ladder[k];
-                const double cx = xs + bx * t, cy = ys + by * t, cz = zs + bz * t;
-                const double ex = cx - px, ey = cy - py, ez = cz - pz;
-                const double r = t * K.sin_2dphi;
-                cand = cand || (((ex * ex + ey * ey) + ez * ez) <= r * r);
-            }
-            if (!cand) continue;
-            if (!have_w) {                                             // ModelResult.py:150-161, oos = 1
-                const double radvel = vy[p] + K.vrplanet;
-                double gg = K.n_lines > 0 ? lut_interp(lut_view(K.line[0]), radvel) : 0.0;
-#pragma unroll
-                for (int l = 1; l < 4; l++)
-                    if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
-                weight = nxc_div_const(frac[p] * gg, 1e6, rs_1e6);   // 1e6 is mid-range
-                if (!(__builtin_fabs(weight) <= 1.7976931348623157e308) || radvel != radvel) my_nonfinite++;
-                have_w = true;
-            }
-            const double ds = dist * K.sin_dphi;
-            const double apix = (3.141592653589793 * (ds * ds)) * K.unit_cm2;   // :194-195
-            double wtemp = nxc_div(weight, apix);
-            const double hx = xs + bx * q, hy = ys + by * q, hz = zs + bz * q;   // :202-206
-            const bool lit = ((hx * hx + hz * hz) > 0x1.0000000000001p+0) || (hy < 0.0);
-            wtemp = lit ? wtemp : wtemp * 0.0;
-            const int64_t i = s0 + j;
-            if (wtemp != 0.0) unsafeAtomicAdd(&radiance[i], wtemp);
-            atomicAdd(&npackets[i], 1ull);
-            my_pairs++;
-            if (included) included[index ? (long long)index[p] - K.index_shift : p] = 1;
-            if (used_pairs && wtemp > 0.0) {
-                const unsigned long long slot = atomicAdd(n_used, 1ull);
-                if ((long long)slot < used_cap) {
-                    used_pairs[slot] = i;
-                    used_pairs[used_cap + slot] = p;
-                }
+    const int64_t nblocks = (P + NXC_LOS_BLOCK - 1) / NXC_LOS_BLOCK;
+    const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + (int)(threadIdx.x >> 6) * NXC_LOSQ_BYTES;
+    LosQueue queue;
+    auto drain = [&]() {               // up to 64 queued candidates, one per lane
+        long long qb = 0;
+        int qj = 0;
+        if (queue.pop(qoff, qb, qj)) {
+            const int64_t q0 = qb * NXC_LOS_BLOCK;
+            const int qn = (int)((P - q0) < NXC_LOS_BLOCK ? (P - q0) : NXC_LOS_BLOCK);
+            for (int s_ = 0; s_ < qn; s_++) {
+                const int64_t p = q0 + s_;
+                los_pair<T, I>(K, tile + qj * 8, s0 + qj, p, (double)x[p], (double)y[p], (double)z[p],
+                               vy, frac, index, ladder, radiance, npackets, included, used_cap,
+                               used_pairs, n_used, rs_1e6, my_pairs, my_nonfinite);
             }
         }
+    };
+    // wave-uniform trip count (the queue is wave-cooperative); the last trip is ragged
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < nblocks;
+         base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t blk = base + threadIdx.x;
+        const bool has = blk < nblocks;
+        double cx = 0, cy = 0, cz = 0, R = 0;
+        bool finite = true;
+        if (has) {
+            const int64_t p0 = blk * NXC_LOS_BLOCK;
+            const int nb = (int)((P - p0) < NXC_LOS_BLOCK ? (P - p0) : NXC_LOS_BLOCK);
+            // bounding sphere: centre of the bounding box, largest distance from it
+            double lox = (double)x[p0], hix = lox, loy = (double)y[p0], hiy = loy, loz = (double)z[p0], hiz = loz;
+            for (int s_ = 1; s_ < nb; s_++) {
+                const double vx_ = (double)x[p0 + s_], vy_ = (double)y[p0 + s_], vz_ = (double)z[p0 + s_];
+                lox = __builtin_fmin(lox, vx_); hix = __builtin_fmax(hix, vx_);
+                loy = __builtin_fmin(loy, vy_); hiy = __builtin_fmax(hiy, vy_);
+                loz = __builtin_fmin(loz, vz_); hiz = __builtin_fmax(hiz, vz_);
+            }
+            cx = 0.5 * (lox + hix); cy = 0.5 * (loy + hiy); cz = 0.5 * (loz + hiz);
+            double R2 = 0.0;
+            bool nan_seen = false;
+            for (int s_ = 0; s_ < nb; s_++) {
+                const double ex = (double)x[p0 + s_] - cx, ey = (double)y[p0 + s_] - cy, ez = (double)z[p0 + s_] - cz;
+                const double e2 = (ex * ex + ey * ey) + ez * ez;
+                nan_seen = nan_seen || e2 != e2;
+                R2 = __builtin_fmax(R2, e2);
+            }
+            // a non-finite coordinate must reach los_pair (it decides such samples like the reference)
+            finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
+            R = finite ? __builtin_sqrt(R2) * (1.0 + 1e-12) : 0.0;
+        }
+        for (int j = 0; j < ns; j++) {
+            bool hit = has;
+            if (has && K.cull && finite) {
+                const double *sp = tile + j * 8;
+                const double rx = cx - sp[0], ry = cy - sp[1], rz = cz - sp[2];
+                const double qc = (rx * sp[3] + ry * sp[4]) + rz * sp[5];
+                const double perp2 = ((rx * rx + ry * ry) + rz * rz) - qc * qc;
+                const double lim = R + (qc + R) * K.tan_dphi;
+                // (slack for the rounding of perp2, whose terms cancel when the centre is near the line)
+                hit = (qc + R > 0.0) && (qc - R < sp[6]) && !(perp2 > lim * lim * (1.0 + 1e-6) + 1e-9);
+            }
+            queue.push(hit, blk, j, qoff);
+            if (queue.waiting() >= 64) drain();
+        }
     }
+    while (queue.waiting() > 0) drain();
     flush_counter(&ctr->samples_binned, my_pairs);
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
