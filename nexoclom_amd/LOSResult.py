@@ -118,8 +118,15 @@ class LOSResult(ModelResult):
 
     def context(self):
         if self._ctx is None:
-            from . import hip_api
-            self._ctx = hip_api.Context(self._device)
+            # the device the catalogued runs were made on, when there is one: their rows are still
+            # in its HBM (and a new handle costs 0.1 s); else a fresh one
+            shared = [getattr(run, '_ctx', None) for run in getattr(self.inputs, '_catalogue', ())]
+            shared = [ctx for ctx in shared if ctx is not None and getattr(ctx, '_h', True)]
+            if shared:
+                self._ctx = shared[-1]
+            else:
+                from . import hip_api
+                self._ctx = hip_api.Context(self._device)
         return self._ctx
 
     def compute_iteration(self, output, scdata, used_cap=0):
