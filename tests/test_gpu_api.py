@@ -201,8 +201,14 @@ def test_los_used_pairs_and_tiles(ctx):
     dphi = np.radians(1.0)
     los = LOSResult(sc, inputs, dphi=dphi, context=ctx)
     out = inputs._catalogue[0]
-    assert out.X.x.dtype == np.float32            # as saved: goes through nxc_los_accumulate_f32
+    assert out.resident_rows(ctx) is not None     # rows in HBM: nxc_los_accumulate_rows
     it = los.compute_iteration(out, sc, used_cap=200000)
+    out._spill()                                  # rows on the host as saved (float32 frame):
+    assert out.X.x.dtype == np.float32 and out.resident_rows(ctx) is None
+    host32 = los.compute_iteration(out, sc, used_cap=200000)      # nxc_los_accumulate_f32
+    assert np.array_equal(host32['npackets'].values, it['npackets'].values)
+    assert np.array_equal(host32['included'], it['included']) and host32['n_used'] == it['n_used']
+    np.testing.assert_allclose(host32['radiance'].values, it['radiance'].values, rtol=1e-12, atol=0)
     X = Output.restore(out).X
     assert out.X.x.dtype == np.float64            # restored: nxc_los_accumulate, same answer
     again = los.compute_iteration(out, sc, used_cap=200000)

@@ -1,5 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 300 python tools/gpu_exp_los_e2e.py 1e6 512 > gpurun_out/r3_los_e2e.log 2>&1
-head -12 gpurun_out/r3_los_e2e.log | cut -c1-160
+timeout -k 10 600 python -m pytest tests/test_gpu_api.py -x -q -m gpu > gpurun_out/r3_t21.log 2>&1
+echo "exit $?" >> gpurun_out/r3_t21.log
+tail -8 gpurun_out/r3_t21.log
