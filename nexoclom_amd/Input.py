@@ -143,7 +143,6 @@ class Input:
         spec = self.surfaceinteraction
         sticks = spec.sticktype == 'constant' and spec.stickcoef == 1.
         together = bool(batch) and keep_trajectory and (compress or self.options.step_size == 0) \
-            and not (sampler == 'device' and self.options.step_size == 0) \
             and (sticks or sampler == 'device')
         if together and context is None:
             from . import hip_api

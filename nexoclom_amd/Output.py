@@ -197,7 +197,7 @@ class Output:
             if integrate:
                 if inputs.options.step_size == 0:
                     print('Running variable step size integrator.')
-                    self.X = self.X0.drop(['longitude', 'latitude', 'local_time'], axis=1)
+                    self.X = self.X0.drop(['longitude', 'latitude', 'local_time'], axis=1, errors='ignore')
                     self.X['lossfrac'] = np.zeros(npackets)
                     self.variable_step_size_driver()
                 else:
@@ -522,7 +522,7 @@ class Output:
         if opt.step_size == 0:
             print('Running variable step size integrator.')
             for out in outputs:
-                out.X = out.X0.drop(['longitude', 'latitude', 'local_time'], axis=1)
+                out.X = out.X0.drop(['longitude', 'latitude', 'local_time'], axis=1, errors='ignore')
                 out.X['lossfrac'] = np.zeros(out.npackets)
                 assert out._bounce is None, 'Not set up'
             ctx.set_forces(**lead.forces_kwargs())
