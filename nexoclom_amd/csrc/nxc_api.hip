@@ -1708,8 +1708,18 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         h->n_packets = 0;
         return code;
     };
+    // piece boundaries: a small first piece (enough to occupy every lane a few times over) lets
+    // the integrator start after a fraction of a millisecond of copying; the rest in equal parts
+    std::vector<int64_t> bound((size_t)pieces + 1, n);
+    bound[0] = 0;
+    if (pieces > 1) {
+        int64_t first = std::max<int64_t>(n / (4 * (int64_t)pieces), (int64_t)h->n_cu * BLOCK_PERSIST * 2);
+        first = std::min(first, n / pieces);
+        for (int p = 1; p < pieces; p++) bound[(size_t)p] = first + (n - first) * (p - 1) / (pieces - 1);
+    }
     for (int p = 0; p < pieces; p++) {
-        const int64_t p0 = n * p / pieces, len = n * (p + 1) / pieces - p0;
+        const int64_t p0 = bound[(size_t)p], len = bound[(size_t)p + 1] - p0;
+        if (len <= 0) continue;
         hipError_t e = hipSuccess;
         for (int c = 0; c < 8 && e == hipSuccess; c++)
             e = hipMemcpyAsync(h->d_packets + c * n + p0, soa0 + c * n + p0, (size_t)len * 8,
