@@ -197,26 +197,42 @@ class Input:
                     drawn += size
                     made += 1
                 if together and outs:
-                    if sampler == 'device' and generator == 'pcg64':
-                        # every Output follows its own seeded stream: one piece of the resident
-                        # set per Output
-                        src, whole = outs[0].source_desc(), size*len(outs)
-                        for g, out in enumerate(outs):
-                            out._adopt_x0(context.sample_packets(
-                                size, seed + made - len(outs) + g, outs[0]._first_index,
-                                download=True, pcg64=(size, 0), piece=(g*size, whole), **src))
-                    elif sampler == 'device':
-                        lead = outs[0]
-                        soa = context.sample_packets(size*len(outs), seed,
-                                                     lead._first_index, download=True,
-                                                     **lead.source_desc())
-                        for g, out in enumerate(outs):
-                            out._adopt_x0(soa[:, g*size:(g + 1)*size])
-                    Output.integrate_batch(outs, context)
+                    self._launch_group(outs, context, sampler, generator, seed, size,
+                                       first_seed=None if seed is None else seed + made - len(outs))
                 print(f'Completed iteration #{number} in {time.time() - tick} seconds.')
             have = self._report()
         self.wait()                              # files of this run are on disk when it returns
         print(f'Model run completed in {time.time() - started:.2f} sec.')
+
+    def _launch_group(self, outs, context, sampler, generator, seed, size, first_seed):
+        """Draw (device samplers) and integrate the Outputs ``outs`` in one launch.  If their rows
+        turn out not to fit in HBM beside what is resident -- the estimate of _group_limit assumes
+        typical lifetimes -- the group is split in halves and tried again."""
+        from . import hip_api
+        from .Output import Output
+        try:
+            if sampler == 'device' and generator == 'pcg64':
+                # every Output follows its own seeded stream: one piece of the resident set each
+                src, whole = outs[0].source_desc(), size*len(outs)
+                for g, out in enumerate(outs):
+                    out._adopt_x0(context.sample_packets(
+                        size, first_seed + g, outs[0]._first_index, download=True,
+                        pcg64=(size, 0), piece=(g*size, whole), **src))
+            elif sampler == 'device':
+                lead = outs[0]
+                soa = context.sample_packets(size*len(outs), seed, lead._first_index,
+                                             download=True, **lead.source_desc())
+                for g, out in enumerate(outs):
+                    out._adopt_x0(soa[:, g*size:(g + 1)*size])
+            Output.integrate_batch(outs, context)
+        except hip_api.HipError as exc:
+            if 'do not fit' not in str(exc) or len(outs) < 2:
+                raise
+            half = len(outs)//2
+            print(f'{len(outs)} Outputs in one launch need more HBM than is free: two launches')
+            self._launch_group(outs[:half], context, sampler, generator, seed, size, first_seed)
+            self._launch_group(outs[half:], context, sampler, generator, seed, size,
+                               None if first_seed is None else first_seed + half)
 
     def _group_limit(self, size, context):
         """How many Outputs of ``size`` packets one launch may take: the packets' states and a

@@ -732,3 +732,40 @@ def test_row_stores_spill_to_the_host_when_hbm_is_needed(ctx):
     with contextlib.redirect_stdout(io.StringIO()):
         inputs.run(4000, packs_per_it=1000, seed=4, context=ctx)
     assert len(inputs._catalogue) == 4 and inputs._catalogue[-1].resident_rows(ctx) is not None
+
+
+@pytest.mark.parametrize('sampler', ['numpy', 'device', 'pcg64'])
+def test_input_run_splits_a_launch_group_whose_rows_do_not_fit(ctx, sampler, monkeypatch):
+    """Input.run sizes its launch groups from an estimate of the rows per packet; when a group's
+    rows do not fit in HBM after all (NXC_ERR_ARG 'do not fit' from the rows protocol) it is split
+    in halves -- drawn again where the device draws -- and the catalogue comes out the same."""
+    from nexoclom_amd import hip_api
+    kw = dict(sampler='device', generator='pcg64') if sampler == 'pcg64' else dict(sampler=sampler)
+
+    def run(limit):
+        inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+        inputs.options.endtime = type(inputs.options.endtime)(6000., 's')
+        real = hip_api.Context.integrate_const_rows
+        calls = []
+
+        def tight(self, *a, **k):
+            calls.append(self.n_packets)
+            if limit and self.n_packets > limit:
+                raise hip_api.HipError('nexoclom_hip error -2: trajectory rows do not fit in '
+                                       'device memory; run fewer packets per call')
+            return real(self, *a, **k)
+        monkeypatch.setattr(hip_api.Context, 'integrate_const_rows', tight)
+        with contextlib.redirect_stdout(io.StringIO()):
+            inputs.run(5000, packs_per_it=1000, seed=12, context=ctx, **kw)
+        monkeypatch.setattr(hip_api.Context, 'integrate_const_rows', real)
+        return inputs, calls
+    whole, calls0 = run(0)
+    split, calls1 = run(1500)
+    assert calls0 == [5000] and calls1 == [5000, 2000, 1000, 1000, 3000, 1000, 2000, 1000, 1000]
+    assert len(whole._catalogue) == len(split._catalogue) == 5
+    for a, b in zip(whole._catalogue, split._catalogue):
+        assert len(a.X) == len(b.X) and a.totalsource == b.totalsource
+        for c in a.X.columns:
+            assert np.array_equal(a.X[c].values, b.X[c].values), c
+        for c in a.X0.columns:
+            assert np.array_equal(a.X0[c].values, b.X0[c].values), c
