@@ -493,7 +493,7 @@ class Context:
             self._h, C.c_double(step), C.c_int64(n_iter), C.c_double(outeredge),
             C.c_uint32(NXC_RUN_IMAGE if image else 0)))
 
-    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=8):
+    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=16):
         """Upload the (8, N) host array and integrate it in one pipelined pass (the next piece
         crosses PCIe while the current one is integrated).  Asynchronous: ``synchronize()`` before
         touching ``soa`` or reading results."""

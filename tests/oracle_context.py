@@ -99,7 +99,7 @@ class OracleContext:
     def integrate_const_async(self, step, n_iter, outeredge, image=True):
         self.integrate_const(step, n_iter, outeredge, image=image)
 
-    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=8):
+    def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=16):
         self.upload_soa(soa)
         self.integrate_const(step, n_iter, outeredge, image=image)
 
