@@ -370,8 +370,11 @@ int upload_blob(nxc_handle *h)
     const size_t hb = NXC_HEADER_BYTES;
     const size_t ib = h->have_image ? h->image_part.size() : 0;
     const size_t limit = 160 * 1024 - 32 - (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES;
+    // (the row-writing kernels stage two more words per queued packet and no image tables)
+    const size_t limit_rows = 160 * 1024 - 32 - (size_t)(BLOCK_PERSIST / 64) * NXC_WAVE_LDS_BYTES_ROWS;
     size_t fb = h->have_forces ? h->force_lut.bytes.size() : 0;
-    while (h->have_forces && hb + fb + ib > limit && h->force_cells_per_node > 2) {
+    while (h->have_forces && (hb + fb + ib > limit || hb + fb > limit_rows) &&
+           h->force_cells_per_node > 2) {
         h->force_cells_per_node /= 2;          // trade lookup hit rate for LDS space
         PackedLut lut;
         int rc2 = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
@@ -382,7 +385,7 @@ int upload_blob(nxc_handle *h)
     }
     h->force_bytes = hb + fb;
     h->all_bytes = hb + fb + ib;
-    if (h->all_bytes > limit)
+    if (h->all_bytes > limit || h->force_bytes > limit_rows)
         return fail(NXC_ERR_ARG, "lookup tables exceed the 160 KiB LDS of a gfx950 CU");
     int rc = ensure(reinterpret_cast<void **>(&h->d_blob), &h->blob_cap, h->all_bytes);
     if (rc) return rc;
