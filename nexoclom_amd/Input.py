@@ -138,12 +138,14 @@ class Input:
         want = int(npackets)
         made = 0
         drawn = have                             # device sampler: next free global packet index
-        # re-emission draws are keyed by (the Output's seed, the packet's number): host-sampled
-        # Outputs each have their own seed, so with re-emission they cannot share a launch
+        # re-emission draws are keyed by (the Output's seed, the packet's number): Outputs that
+        # each have their own seed (host-sampled, or following the host streams with 'pcg64')
+        # cannot share a launch when packets are re-emitted
         spec = self.surfaceinteraction
         sticks = spec.sticktype == 'constant' and spec.stickcoef == 1.
+        one_key = sampler == 'device' and generator != 'pcg64'
         together = bool(batch) and keep_trajectory and (compress or self.options.step_size == 0) \
-            and (sticks or sampler == 'device')
+            and (sticks or one_key)
         if together and context is None:
             from . import hip_api
             context = hip_api.Context(device)

@@ -654,16 +654,16 @@ class Output:
             out = source
             out.X0, out.X = cls.upcast(out.X0), cls.upcast(out.X)
             return out
-        data = np.load(source, allow_pickle=False)
         out = cls.__new__(cls)
         out.filename = source
-        out.npackets = int(data['npackets'])
-        out.totalsource = float(data['totalsource'])
-        out.nsteps = int(data['nsteps'])
-        out.aplanet = Quantity(float(data['aplanet']), 'au')
-        out.vrplanet = Quantity(float(data['vrplanet_kms']), 'km/s')
-        out.compress = bool(data['compress'])
-        out.X0 = pd.DataFrame({k[3:]: data[k] for k in data.files if k.startswith('X0.')})
-        out.X = pd.DataFrame({k[2:]: data[k] for k in data.files if k.startswith('X.')})
+        with np.load(source, allow_pickle=False) as data:
+            out.npackets = int(data['npackets'])
+            out.totalsource = float(data['totalsource'])
+            out.nsteps = int(data['nsteps'])
+            out.aplanet = Quantity(float(data['aplanet']), 'au')
+            out.vrplanet = Quantity(float(data['vrplanet_kms']), 'km/s')
+            out.compress = bool(data['compress'])
+            out.X0 = pd.DataFrame({k[3:]: data[k] for k in data.files if k.startswith('X0.')})
+            out.X = pd.DataFrame({k[2:]: data[k] for k in data.files if k.startswith('X.')})
         out.X0, out.X = cls.upcast(out.X0), cls.upcast(out.X)
         return out
