@@ -65,6 +65,20 @@ def test_random_configuration_parity(ctx, coracle, seed):
     t = ctx.integrate_const(step, n_iter, outeredge, nrec=nsteps, want_final=True)
     ct = coracle.integrate_const(f, X0[:m], step, n_iter, outeredge, nrec=nsteps)
     assert np.array_equal(t['traj'], ct['traj'])
+    # the compact rows (what save() keeps, Output.py:523-543): 64-bit, narrowed on the device, and
+    # as a resident store with its packet-index column
+    live = ct['traj'][7].T > 0                                           # (m, nsteps)
+    ctx.upload_packets(X0[:m])
+    wide = ctx.integrate_const_rows(step, n_iter, outeredge)
+    assert ctx.counters()['unfinished'] == 0
+    assert np.array_equal(wide['lengths'], live.sum(1))
+    for col in range(8):
+        assert np.array_equal(wide['rows'][col], ct['traj'][col].T[live])
+    store = ctx.integrate_const_rows(step, n_iter, outeredge, narrow=True, resident=True)['store']
+    rows32, index = store.download()
+    store.free()
+    assert np.array_equal(rows32, wide['rows'].astype(np.float32))
+    assert np.array_equal(index, np.repeat(np.arange(m), wide['lengths']))
     # and one adaptive run
     Xv = X0[:m].copy()
     Xv[:, 0] = rng.random(m)*endtime
