@@ -543,7 +543,7 @@ FusedJob whole_set(nxc_handle *h)
     return j;
 }
 
-template <bool IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false, bool STREAMED = false>
+template <int IMAGE, bool BOUNCE, bool FULL = false, bool NBODY = false, bool STREAMED = false>
 int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2,
                  double *d_final, long long *d_steps, const FusedJob &job)
 {
@@ -561,26 +561,24 @@ int launch_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, doubl
     return job.timed ? end_timed(h) : NXC_OK;
 }
 
-// The kernel variant for the handle's force model / re-emission / moons.
+// The kernel variant for the handle's force model / re-emission / moons.  Image: 1 = samples
+// binned as they are (64-bit), 2 = binned as the float32 values save() stores (nxc_image_desc.
+// downcast_f32): the frame test comes before the compaction queue, everything else after it.
 int pick_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double edge2, bool image,
                double *d_final, long long *d_steps, const FusedJob &job)
 {
-#define NXC_FUSED(...) launch_fused<__VA_ARGS__>(h, tables, lds, n_iter, edge2, d_final, d_steps, job)
-    if (job.avail) {        // streamed upload: the plain force models only (checked by the caller)
-        const bool full_ = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
-        if (full_) return image ? NXC_FUSED(true, false, true, false, true) : NXC_FUSED(false, false, true, false, true);
-        return image ? NXC_FUSED(true, false, false, false, true) : NXC_FUSED(false, false, false, false, true);
-    }
-    if (h->have_bodies) {
-        if (h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO)
-            return image ? NXC_FUSED(true, false, true, true) : NXC_FUSED(false, false, true, true);
-        return image ? NXC_FUSED(true, false, false, true) : NXC_FUSED(false, false, false, true);
-    }
-    // gravity + radiation pressure + photo-loss, no re-emission: the compile-time specialisation
-    const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO && !h->have_bounce;
-    if (full) return image ? NXC_FUSED(true, false, true) : NXC_FUSED(false, false, true);
-    if (image) return h->have_bounce ? NXC_FUSED(true, true) : NXC_FUSED(true, false);
-    return h->have_bounce ? NXC_FUSED(false, true) : NXC_FUSED(false, false);
+    const int img = image ? (h->G.downcast_f32 ? 2 : 1) : 0;
+#define NXC_FUSED(...)                                                                              \
+    (img == 2 ? launch_fused<2, __VA_ARGS__>(h, tables, lds, n_iter, edge2, d_final, d_steps, job)  \
+     : img == 1 ? launch_fused<1, __VA_ARGS__>(h, tables, lds, n_iter, edge2, d_final, d_steps, job) \
+                : launch_fused<0, __VA_ARGS__>(h, tables, lds, n_iter, edge2, d_final, d_steps, job))
+    // gravity + radiation pressure + photo-loss: the compile-time specialisation of the force model
+    const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
+    if (job.avail)          // streamed upload: the plain force models only (checked by the caller)
+        return full ? NXC_FUSED(false, true, false, true) : NXC_FUSED(false, false, false, true);
+    if (h->have_bodies) return full ? NXC_FUSED(false, true, true) : NXC_FUSED(false, false, true);
+    if (h->have_bounce) return NXC_FUSED(true, false);
+    return full ? NXC_FUSED(false, true) : NXC_FUSED(false, false);
 #undef NXC_FUSED
 }
 
@@ -610,7 +608,7 @@ template <bool BOUNCE, bool FULL, bool NBODY, int ROWS>
 int launch_rows(nxc_handle *h, int64_t n_iter, double edge2, void *d_rec)
 {
     int grid = 1, block = BLOCK_PERSIST, rc;
-    auto kernel = k_const_fused<false, BOUNCE, FULL, NBODY, ROWS>;
+    auto kernel = k_const_fused<0, BOUNCE, FULL, NBODY, ROWS>;
     const size_t tables = h->force_bytes, lds = persist_lds_rows(tables);
     if ((rc = prep_kernel(kernel, lds))) return rc;
     if ((rc = persistent_grid(h, kernel, &block, lds, h->n_packets, &grid))) return rc;
@@ -1125,6 +1123,7 @@ int nxc_set_image(nxc_handle *h, const nxc_image_desc *d)
     const int nl = d->quantity == 1 ? d->n_lines : 0;
     if (nl < 0 || nl > NXC_MAX_LINES) return fail(NXC_ERR_ARG, "n_lines out of range");
     if (!(d->apix_cm2 > 0)) return fail(NXC_ERR_ARG, "apix_cm2 must be positive");
+    if (!std::isfinite(d->vrplanet)) return fail(NXC_ERR_ARG, "vrplanet must be finite");
     for (int64_t k = 0; k < d->nx; k++)
         if (!(d->xedges[k + 1] > d->xedges[k])) return fail(NXC_ERR_ARG, "xedges not ascending");
     for (int64_t k = 0; k < d->nz; k++)

@@ -791,14 +791,10 @@ NXC_DEV void image_add_pairs(bool has, int pix, double w, double *__restrict__ a
 //   image_weight: weight of a located sample (ModelResult.py:148-161, ModelImage.py:262); false
 //                 when it is not finite (the reference asserts, ModelResult.py:170; here the
 //                 sample is counted in `nonfinite` and never reaches a pixel).
-NXC_DEV int image_locate(const ImageK &G, const ImageRegs &R, double x, double y, double z,
-                         double vy, double frac, double &radvel_out, double &fw_out,
-                         unsigned long long &nonfinite)
+NXC_DEV int image_locate_core(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                              double vy, double frac, double &radvel_out, double &fw_out,
+                              unsigned long long &nonfinite)
 {
-    if (R.downcast) {
-        x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
-        vy = f32_round_trip(vy); frac = f32_round_trip(frac);
-    }
     const double radvel = vy + R.vrplanet;                         // ModelImage.py:242-243
     double xo, yo, zo;                                             // ModelImage.py:249
     if (R.x_is_x) {
@@ -827,6 +823,44 @@ NXC_DEV int image_locate(const ImageK &G, const ImageRegs &R, double x, double y
     radvel_out = radvel;
     fw_out = frac;
     return ix * R.nz + iz;
+}
+
+NXC_DEV int image_locate(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                         double vy, double frac, double &radvel_out, double &fw_out,
+                         unsigned long long &nonfinite)
+{
+    if (R.downcast) {
+        x = f32_round_trip(x); y = f32_round_trip(y); z = f32_round_trip(z);
+        vy = f32_round_trip(vy); frac = f32_round_trip(frac);
+    }
+    return image_locate_core(G, R, x, y, z, vy, frac, radvel_out, fw_out, nonfinite);
+}
+
+// The down-cast image path in the persistent kernel, stage 0: is the sample inside the image
+// frame at all?  Only the float32 round trip of the position, the two observer-frame coordinates
+// the bins are taken from and the range test of bin_index -- exactly the samples image_locate
+// returns -1 for are turned away here, with the same bookkeeping: outside the image the weight is
+// not formed, and it is finite iff the stored (float32) frac and vy are, i.e. iff |frac| is below
+// the value that rounds to float infinity (2^128 - 2^103) and vy is not NaN (vrplanet is finite:
+// nxc_set_image).  The sample then waits in the queue as the five float32 values save() would
+// store; the rest (image_locate_core, image_weight) runs on full waves after the queue.
+NXC_DEV bool image_frame_test(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                              double vy, double frac, float &xf, float &yf, float &zf,
+                              unsigned long long &nonfinite)
+{
+    xf = (float)x; yf = (float)y; zf = (float)z;
+    const double xd = xf, yd = yf, zd = zf;
+    double xo, zo;
+    if (R.x_is_x) {
+        xo = xd;
+        zo = G.M[7] * yd + G.M[8] * zd;
+    } else {
+        xo = (G.M[0] * xd + G.M[1] * yd) + G.M[2] * zd;
+        zo = (G.M[6] * xd + G.M[7] * yd) + G.M[8] * zd;
+    }
+    const bool inside = (xo >= R.x_lo) && (xo <= R.x_hi) && (zo >= R.z_lo) && (zo <= R.z_hi);
+    if (!inside && (!(__builtin_fabs(frac) < 0x1.ffffffp127) || vy != vy)) nonfinite++;
+    return inside;
 }
 
 NXC_DEV bool image_weight(const ImageK &G, const ImageRegs &R, double radvel, double fw,
@@ -896,6 +930,38 @@ struct ImageQueue {
         tail += __popcll(m);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    // the same ring holding the five float32 values of a sample that passed image_frame_test
+    NXC_DEV void push_sample(bool has, float x, float y, float z, float vy, float frac, int qoff)
+    {
+        const unsigned long long m = __ballot(has);
+        if (m == 0) return;
+        if (has) {
+            const int lane = threadIdx.x & 63;
+            const int slot = (tail + __popcll(m & ((1ull << lane) - 1ull))) & (NXC_IMGQ_SLOTS - 1);
+            float *q = reinterpret_cast<float *>(nxc_lds + qoff) + slot;
+            q[0] = x; q[NXC_IMGQ_SLOTS] = y; q[2 * NXC_IMGQ_SLOTS] = z;
+            q[3 * NXC_IMGQ_SLOTS] = vy; q[4 * NXC_IMGQ_SLOTS] = frac;
+        }
+        tail += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    NXC_DEV bool pop_sample(int qoff, double &x, double &y, double &z, double &vy, double &frac)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = waiting() < 64 ? waiting() : 64;
+        const int lane = threadIdx.x & 63;
+        const bool mine = lane < n;
+        if (mine) {
+            const int slot = (head + lane) & (NXC_IMGQ_SLOTS - 1);
+            const float *q = reinterpret_cast<const float *>(nxc_lds + qoff) + slot;
+            x = q[0]; y = q[NXC_IMGQ_SLOTS]; z = q[2 * NXC_IMGQ_SLOTS];
+            vy = q[3 * NXC_IMGQ_SLOTS]; frac = q[4 * NXC_IMGQ_SLOTS];
+        }
+        head += n;
+        __builtin_amdgcn_wave_barrier();
+        return mine;
     }
     NXC_DEV int waiting() const { return tail - head; }
     // every lane below min(64, waiting) receives a sample; returns whether this lane did

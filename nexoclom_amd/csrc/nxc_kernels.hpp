@@ -414,13 +414,29 @@ struct WaveQueue {
     }
 };
 
+// One sample per lane off the image queue, located: pixel, radial velocity and masked fraction.
+// IMAGE == 1: the queue holds located samples; IMAGE == 2: it holds the float32 samples that passed
+// image_frame_test, and the rest of image_locate happens here, on full waves.
+template <int IMAGE>
+NXC_DEV bool image_pop(ImageQueue &queue, int imgq_off, const ImageRegs &IR, int &p, double &rv,
+                       double &fw, unsigned long long &nonfinite)
+{
+    if (IMAGE == 2) {
+        double x = 0, y = 0, z = 0, vy = 0, frac = 0;
+        const bool ok = queue.pop_sample(imgq_off, x, y, z, vy, frac);
+        if (ok) p = image_locate_core(lds_header().G, IR, x, y, z, vy, frac, rv, fw, nonfinite);
+        return ok && p >= 0;
+    }
+    return queue.pop(imgq_off, p, rv, fw);
+}
+
 // Persistent lane-refill constant-step integrator (+ fused image).  The grid is sized to the
 // machine (blocks = CUs x resident blocks), not to n; every wave leaves its loop when the queue
 // is drained and none of its lanes holds a live packet.
 // ROWS != 0 (never with IMAGE): every live record -- the initial state and the state after each step
 // while frac > 0 -- goes to row offsets[id] + k of rec[total][10] (doubles, or floats for ROWS = 2) with lossfrac accumulated as
 // (lossfrac + frac_before) - frac_after per step (Output.py:420-421) from 0.
-template <bool IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, int ROWS = 0, bool STREAMED = false>
+template <int IMAGE, bool BOUNCE, bool FULL, bool NBODY = false, int ROWS = 0, bool STREAMED = false>
 __global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
               int64_t stage_bytes, int64_t n, const double *__restrict__ soa0,
@@ -480,6 +496,8 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         NXC_STAMP(0);                                  // refill
         int p = -1;
         double rv = 0.0, fw = 0.0;
+        bool inframe = false;                          // IMAGE == 2: the sample as save() stores it
+        float qx = 0.f, qy = 0.f, qz = 0.f;
         if (has) {
             const double before = s[7];
             if (!fresh) {
@@ -523,8 +541,12 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
             }
             if (IMAGE && live) {
                 my_samples++;
-                p = image_locate(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], rv, fw,
-                                 my_nonfinite);
+                if (IMAGE == 2)
+                    inframe = image_frame_test(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], qx,
+                                               qy, qz, my_nonfinite);
+                else
+                    p = image_locate(lds_header().G, IR, s[1], s[2], s[3], s[5], s[7], rv, fw,
+                                     my_nonfinite);
             }
             NXC_STAMP(2);                              // locate
             if (!live || k >= n_it) {
@@ -545,13 +567,14 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 #ifdef NXC_EXPERIMENT_KNOBS
             // timing experiments (tools/gpu_exp_dbg.py): 3 = locate only, 2 = + queue, no weight,
             // 1 = everything but the atomics
-            if (IR.dbg == 3) { my_binned += p >= 0; continue; }
+            if (IR.dbg == 3) { my_binned += IMAGE == 2 ? inframe : p >= 0; continue; }
 #endif
-            queue.push(p >= 0, p, rv, fw, imgq_off);
+            if (IMAGE == 2) queue.push_sample(inframe, qx, qy, qz, (float)s[5], (float)s[7], imgq_off);
+            else queue.push(p >= 0, p, rv, fw, imgq_off);
             NXC_STAMP(4);                              // push
             if (queue.waiting() >= 64) {
                 double w = 0.0;
-                bool ok = queue.pop(imgq_off, p, rv, fw);
+                bool ok = image_pop<IMAGE>(queue, imgq_off, IR, p, rv, fw, my_nonfinite);
 #ifdef NXC_EXPERIMENT_KNOBS
                 if (IR.dbg == 2) { my_binned += ok; continue; }
 #endif
@@ -574,7 +597,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         while (queue.waiting() > 0) {
             int p = -1;
             double rv = 0.0, fw = 0.0, w = 0.0;
-            bool ok = queue.pop(imgq_off, p, rv, fw);
+            bool ok = image_pop<IMAGE>(queue, imgq_off, IR, p, rv, fw, my_nonfinite);
             if (ok && !image_weight(lds_header().G, IR, rv, fw, w)) { my_nonfinite++; ok = false; }
             my_binned += ok;
             image_add_pairs(ok, p, w, acc2);

@@ -81,7 +81,7 @@ def classify(op):
 
 def main():
     want = next((a for a in sys.argv[1:] if not a.startswith('--')),
-                'k_const_fusedILb1ELb0ELb1ELb0E')
+                'k_const_fusedILi2ELb0ELb1ELb0E')
     from nexoclom_amd import build as B
     flags = [f for f in B.FLAGS if f not in ('-shared', '-fPIC')]
     with tempfile.TemporaryDirectory() as tmp:
