@@ -35,7 +35,7 @@ import pandas as pd
 
 from .atomicdata import LossInfo, RadPresConst
 from .solarsystem import planet_dist
-from .source_distribution import (angular_distribution, speed_distribution,
+from .source_distribution import (LaunchTable, angular_distribution, speed_distribution,
                                   surface_distribution)
 from .units import Quantity, register_unit
 
@@ -141,7 +141,8 @@ class Output:
             self._first_index = first_index
 
             self.npackets = npackets
-            self.X0 = pd.DataFrame()
+            # the host sampler fills a table of plain columns; the frame is built once at the end
+            self.X0 = LaunchTable(npackets) if sampler == 'numpy' else pd.DataFrame()
             if sampler == 'device':
                 # the device draws everything, launch times included; host columns of npackets
                 # rows (0.2 s per 2e7) are built only when the caller wants X0 back
@@ -184,10 +185,10 @@ class Output:
                     assert 0, 'Not a valid spatial distribution type'
                 speed_distribution(self)
                 angular_distribution(self)
+                self._launch_from_moon()
                 cols = ['time', 'x', 'y', 'z', 'vx', 'vy', 'vz', 'frac', 'v',
                         'longitude', 'latitude', 'local_time', 'altitude', 'azimuth']
-                self.X0 = self.X0[cols]
-                self._launch_from_moon()
+                self.X0 = self.X0.frame(cols)
             else:
                 raise ValueError("sampler must be 'numpy' or 'device'")
             self.nsteps = None
@@ -329,15 +330,15 @@ class Output:
         mo = next((m for m in self._bodies['moons'] if m['name'] == geo.startpoint), None)
         assert mo is not None, 'geometry.startpoint must be one of geometry.objects'
         X0 = self.X0
-        ang = mo['phi'] - mo['omega']*X0['time'].values
+        ang = mo['phi'] - mo['omega']*X0['time']
         c, s_ = np.cos(ang), np.sin(ang)
-        xl, yl = X0['x'].values*mo['radius'], X0['y'].values*mo['radius']
+        xl, yl = X0['x']*mo['radius'], X0['y']*mo['radius']
         xr, yr = c*xl - s_*yl, s_*xl + c*yl
-        vxl, vyl = X0['vx'].values, X0['vy'].values
+        vxl, vyl = X0['vx'], X0['vy']
         aw = mo['a']*mo['omega']
         X0['x'] = xr - mo['a']*s_
         X0['y'] = yr + mo['a']*c
-        X0['z'] = X0['z'].values*mo['radius']
+        X0['z'] = X0['z']*mo['radius']
         X0['vx'] = (c*vxl - s_*vyl) - aw*c - mo['omega']*yr
         X0['vy'] = (s_*vxl + c*vyl) - aw*s_ + mo['omega']*xr
 

@@ -65,6 +65,34 @@ class WindowGenerator:
         return not gaussian
 
 
+class LaunchTable(dict):
+    """X0 while it is being drawn: plain arrays by column name.  (Every column inserted into a
+    pandas frame costs about a millisecond with the GIL held -- a third of the time it takes to
+    draw an Output of 8e4 packets, and what kept several Outputs from being drawn side by side;
+    Output builds the frame once, from the finished table.)  Scalars are broadcast like pandas
+    broadcasts them."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.n = int(n)
+
+    def __setitem__(self, name, value):
+        column = np.asarray(value)
+        if column.ndim == 0:
+            column = np.full(self.n, column)
+        super().__setitem__(name, column)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def frame(self, columns):
+        import pandas as pd
+        return pd.DataFrame({c: self[c] for c in columns}, copy=False)
+
+
 # ---- geometry helpers ---------------------------------------------------------------------------
 def xyz_from_lonlat(lon, lat, isplan, exobase):
     """Surface point of longitude/latitude on the sphere r = exobase, as a (3, n) array
@@ -297,8 +325,8 @@ def angular_distribution(outputs):
     assert ad.type in DIRECTIONS, 'Angular Distribution not defined.'
     alt, az = DIRECTIONS[ad.type](outputs, ad)
     X0 = outputs.X0
-    x, y, z = (X0[c].values for c in ('x', 'y', 'z'))
-    speed = X0.v.values
+    x, y, z = (np.asarray(X0[c]) for c in ('x', 'y', 'z'))
+    speed = np.asarray(X0['v'])
     up, level = np.sin(alt), np.cos(alt)
     if ad.type == '2d':
         outward = _unit_rows(np.array([x, y]).transpose())
