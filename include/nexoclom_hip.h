@@ -317,6 +317,9 @@ int nxc_rows_build(nxc_handle *h, int narrow, nxc_rows **out);
 int nxc_rows_info(const nxc_rows *r, int64_t *total, int32_t *is_f32);
 int nxc_rows_download(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count,
                       void *cols_out, void *index_out);
+/* Frees the store.  Its two device blocks (when large) are kept by the handle for the next store of
+ * about the same size -- hipFree / hipMalloc of tens of GB cost seconds -- and go back to the driver
+ * when anything else needs the memory; nxc_mem_info counts them as free. */
 int nxc_rows_free(nxc_handle *h, nxc_rows *r);
 int nxc_image_accumulate_rows(nxc_handle *h, const nxc_rows *r, int64_t first, int64_t count);
 /* Same launch without any host transfer or synchronisation (bench / pipelining). */

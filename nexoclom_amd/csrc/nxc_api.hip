@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -271,6 +272,17 @@ struct nxc_rows {
     long long total = 0;
     void *d_cols = nullptr;
     void *d_index = nullptr;
+    size_t cols_cap = 0, index_cap = 0;      // bytes of the two blocks (they may come from the pool)
+};
+
+// Device blocks of freed row stores, kept for the next store: hipFree / hipMalloc of tens of GB
+// cost about a second per 60 GB (a catalogue that is dropped and re-run pays it twice).  The pool
+// counts as free memory (nxc_mem_info) and is emptied before anything is refused for lack of it.
+struct BlockPool {
+    struct Block { void *p; size_t bytes; };
+    std::vector<Block> blocks;
+    size_t bytes = 0;
+    std::mutex lock;                         // stores are freed by whichever thread drops them
 };
 
 struct nxc_handle {
@@ -330,6 +342,8 @@ struct nxc_handle {
     void *d_rec = nullptr;           // pass 2's records on their way to columns (grow-only)
     size_t rec_cap = 0;
 
+    BlockPool pool;
+
     // compact-rows protocol (nxc_integrate_const_rows -> nxc_rows_fetch)
     long long *d_offsets = nullptr;
     size_t offsets_cap = 0;
@@ -352,15 +366,92 @@ static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifet
 
 namespace {
 
+void flush_all_pools();
+
 int ensure(void **ptr, size_t *cap, size_t bytes)
 {
     if (*cap >= bytes && *ptr) return NXC_OK;
     if (*ptr) HIPCHK(hipFree(*ptr));
     *ptr = nullptr;
     *cap = 0;
-    HIPCHK(hipMalloc(ptr, bytes ? bytes : 8));
+    if (hipMalloc(ptr, bytes ? bytes : 8) != hipSuccess) {
+        (void)hipGetLastError();
+        flush_all_pools();                 // memory kept from freed row stores goes back first
+        HIPCHK(hipMalloc(ptr, bytes ? bytes : 8));
+    }
     *cap = bytes;
     return NXC_OK;
+}
+
+void pool_flush(nxc_handle *h)
+{
+    std::lock_guard<std::mutex> g(h->pool.lock);
+    for (const auto &b : h->pool.blocks) (void)hipFree(b.p);
+    h->pool.blocks.clear();
+    h->pool.bytes = 0;
+}
+
+// A block of at least `bytes`: the best fit in the pool that wastes less than a quarter, else new
+// memory (the pool is given back to the driver before an allocation is allowed to fail).
+hipError_t pool_take(nxc_handle *h, size_t bytes, void **out, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> g(h->pool.lock);
+        int best = -1;
+        for (int k = 0; k < (int)h->pool.blocks.size(); k++) {
+            const size_t have = h->pool.blocks[(size_t)k].bytes;
+            if (have >= bytes && have - bytes <= bytes / 4 &&
+                (best < 0 || have < h->pool.blocks[(size_t)best].bytes))
+                best = k;
+        }
+        if (best >= 0) {
+            *out = h->pool.blocks[(size_t)best].p;
+            *cap = h->pool.blocks[(size_t)best].bytes;
+            h->pool.bytes -= *cap;
+            h->pool.blocks.erase(h->pool.blocks.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        pool_flush(h);
+        e = hipMalloc(out, bytes ? bytes : 8);
+    }
+    *cap = e == hipSuccess ? bytes : 0;
+    return e;
+}
+
+void pool_give(nxc_handle *h, void *p, size_t bytes)
+{
+    if (!p) return;
+    size_t free_b = 0, total_b = 0;
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    std::lock_guard<std::mutex> g(h->pool.lock);
+    // small blocks are cheap to allocate; the pool never holds more than a third of the device
+    if (!known || bytes < (size_t(64) << 20) || h->pool.bytes + bytes > total_b / 3 ||
+        h->pool.blocks.size() >= 64) {
+        (void)hipFree(p);
+        return;
+    }
+    h->pool.blocks.push_back({p, bytes});
+    h->pool.bytes += bytes;
+}
+
+// every live handle, for allocations that have no handle at hand (ensure)
+std::mutex g_handles_lock;
+std::vector<nxc_handle *> g_handles;
+
+void flush_all_pools()
+{
+    std::lock_guard<std::mutex> g(g_handles_lock);
+    for (nxc_handle *h : g_handles) pool_flush(h);
+}
+
+size_t pool_bytes(nxc_handle *h)
+{
+    std::lock_guard<std::mutex> g(h->pool.lock);
+    return h->pool.bytes;
 }
 
 // Device blob = [LdsHeader | force table | g-value tables | x edges | z edges]; kernels stage
@@ -681,10 +772,16 @@ int write_records(nxc_handle *h, bool narrow, size_t reserve)
     const size_t bytes = (size_t)total * 10 * (narrow ? sizeof(float) : sizeof(double));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    if ((bytes > h->rec_cap ? bytes : 0) + reserve > free_b + (bytes > h->rec_cap ? h->rec_cap : 0))
+    const size_t grow = bytes > h->rec_cap ? bytes : 0, back = grow ? h->rec_cap : 0;
+    if (grow + reserve > free_b + back + pool_bytes(h))
         return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
                                  "per call (the reference chunks too, Input.py:219-222)");
-    if ((rc = ensure(&h->d_rec, &h->rec_cap, bytes))) return rc;
+    if (grow > free_b + back) pool_flush(h);      // the scratch grows into what the pool holds
+    // the launch groups of an Input.run differ by a per cent or so: an eighth of slack saves the
+    // later ones a free + malloc of ten-odd GB each
+    const size_t roomy = bytes + bytes / 8;
+    const bool slack = grow && roomy + reserve <= free_b + back;
+    if ((rc = ensure(&h->d_rec, &h->rec_cap, slack ? roomy : bytes))) return rc;
     if (h->have_bodies) {
         if (h->have_bounce)
             return fail(NXC_ERR_STATE, "surface re-emission is not available with moons set");
@@ -733,8 +830,8 @@ int rows_build(nxc_handle *h, bool narrow, nxc_rows **out)
     r->device = h->device; r->f32 = narrow; r->total = total;
     hipError_t e = hipSuccess;
     if (total > 0) {
-        e = hipMalloc(&r->d_cols, cols_bytes);
-        if (e == hipSuccess) e = hipMalloc(&r->d_index, idx_bytes);
+        e = pool_take(h, cols_bytes, &r->d_cols, &r->cols_cap);
+        if (e == hipSuccess) e = pool_take(h, idx_bytes, &r->d_index, &r->index_cap);
         if (e == hipSuccess)
             rc = narrow ? transpose_rows<float, int>(h, h->d_rec, total, r->d_cols, r->d_index)
                         : transpose_rows<double, long long>(h, h->d_rec, total, r->d_cols, r->d_index);
@@ -1013,6 +1110,10 @@ int nxc_create(int device, nxc_handle **out)
         nxc_destroy(h);
         return fail(NXC_ERR_HIP, std::string("nxc_create: ") + hipGetErrorString(e));
     }
+    {
+        std::lock_guard<std::mutex> g(g_handles_lock);
+        g_handles.push_back(h);
+    }
     *out = h;
     return NXC_OK;
     });
@@ -1021,6 +1122,10 @@ int nxc_create(int device, nxc_handle **out)
 int nxc_destroy(nxc_handle *h)
 {
     if (!h) return NXC_OK;
+    {
+        std::lock_guard<std::mutex> g(g_handles_lock);
+        g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end());
+    }
     (void)hipSetDevice(h->device);
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1029,6 +1134,7 @@ int nxc_destroy(nxc_handle *h)
                     h->d_source, h->d_queue, h->d_samples, h->d_hist, h->d_rec, h->d_piece_hist};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    pool_flush(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -1060,6 +1166,7 @@ int nxc_mem_info(nxc_handle *h, uint64_t *free_bytes, uint64_t *total_bytes)
     HIPCHK(hipSetDevice(h->device));
     size_t f = 0, t = 0;
     HIPCHK(hipMemGetInfo(&f, &t));
+    f += pool_bytes(h);          // blocks kept from freed row stores are reused or given back on demand
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
     return NXC_OK;
@@ -1786,6 +1893,10 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         const size_t tbytes = (size_t)8 * (size_t)nrec * col;
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        if (tbytes > free_b && pool_bytes(h)) {
+            pool_flush(h);
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        }
         if (tbytes > free_b)
             return fail(NXC_ERR_ARG, "trajectory buffer does not fit in device memory; run fewer "
                                      "packets per call (the reference chunks too, Input.py:219-222)");
@@ -1874,8 +1985,13 @@ int nxc_rows_free(nxc_handle *h, nxc_rows *r)
     (void)hipSetDevice(r->device);
     if (h && h->stream) (void)hipStreamSynchronize(h->stream);
     if (h && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-    if (r->d_cols) (void)hipFree(r->d_cols);
-    if (r->d_index) (void)hipFree(r->d_index);
+    if (h && h->device == r->device) {
+        pool_give(h, r->d_cols, r->cols_cap);
+        pool_give(h, r->d_index, r->index_cap);
+    } else {
+        if (r->d_cols) (void)hipFree(r->d_cols);
+        if (r->d_index) (void)hipFree(r->d_index);
+    }
     delete r;
     return NXC_OK;
 }

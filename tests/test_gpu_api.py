@@ -734,6 +734,39 @@ def test_row_stores_spill_to_the_host_when_hbm_is_needed(ctx):
     assert len(inputs._catalogue) == 4 and inputs._catalogue[-1].resident_rows(ctx) is not None
 
 
+def test_blocks_of_freed_row_stores_are_reused(ctx, coracle):
+    """A freed store's device blocks wait in the handle for the next store of about that size
+    (nxc_rows_free); they count as free memory, are handed out again with the new rows intact,
+    and go back to the driver when something else needs the memory (not forced here)."""
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    endtime, step = 9000., 30.
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    X0 = H.sample_x0(400_000, 5, endtime)            # ~3e7 rows: blocks well above the pool's floor
+
+    def rows(n):
+        ctx.upload_packets(X0[:n])
+        res = ctx.integrate_const_rows(step, n_iter, 25., narrow=True, resident=True)
+        return res['store'], res['lengths']
+
+    store, lengths = rows(len(X0))
+    first = store.download(0, 5000)
+    free_with_store = ctx.mem_info()[0]
+    nbytes = store.nbytes
+    store.free()
+    assert ctx.mem_info()[0] >= free_with_store + nbytes*0.99          # pooled = free
+    again, lengths2 = rows(len(X0) - 1000)           # a little smaller: takes the pooled blocks
+    assert again.total == lengths2.sum() and np.array_equal(lengths2, lengths[:-1000])
+    second = again.download(0, 5000)
+    assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
+    again.free()
+    # with blocks waiting in the pool every other path works as before
+    ctx.upload_packets(X0[:2000])
+    dense = ctx.integrate_const(step, n_iter, 25., nrec=nsteps)['traj']
+    c = coracle.integrate_const(f, X0[:2000], step, n_iter, 25., nrec=nsteps)
+    assert np.array_equal(dense, c['traj'])
+
+
 @pytest.mark.parametrize('sampler', ['numpy', 'device', 'pcg64'])
 def test_input_run_splits_a_launch_group_whose_rows_do_not_fit(ctx, sampler, monkeypatch):
     """Input.run sizes its launch groups from an estimate of the rows per packet; when a group's
