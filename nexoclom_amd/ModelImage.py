@@ -205,13 +205,27 @@ class ModelImage(ModelResult):
         (aplanet, vrplanet_kms), = same
         self._set_image(ctx, aplanet, vrplanet_kms/self.unit_km, downcast=False)    # clears it
         totals = {}
-        for run, (store, first, count, _) in zip(runs, views):
-            print(f'Output filename: {run.filename}')
+
+        def accumulate(store, first, count):
             if count:
                 ctx.image_accumulate_rows(store, first, count)
                 for key, v in ctx.counters().items():
                     totals[key] = totals.get(key, 0) + v
+
+        # the Outputs of a launch group are consecutive slices of one store: one kernel launch per
+        # run of adjacent slices instead of one per Output
+        span = None                               # (store, first row, row count)
+        for run, (store, first, count, _) in zip(runs, views):
+            print(f'Output filename: {run.filename}')
+            if span is not None and span[0] is store and span[1] + span[2] == first:
+                span = (store, span[1], span[2] + count)
+            else:
+                if span is not None:
+                    accumulate(*span)
+                span = (store, first, count)
             self.totalsource += run.totalsource
+        if span is not None:
+            accumulate(*span)
         self.counters = totals
         assert totals.get('nonfinite', 0) == 0, 'Non-finite weights'
         image, counts = ctx.image_download()

@@ -312,6 +312,8 @@ struct nxc_handle {
     int64_t xedges_local = 0, zedges_local = 0;
     unsigned char *d_blob = nullptr;
     size_t blob_cap = 0, force_bytes = 0, all_bytes = 0;
+    unsigned char *d_blob_img = nullptr;         // [LdsHeader | image part] for the kernels that bin
+    size_t blob_img_cap = 0, img_bytes = 0;      // stored samples: no force table in their LDS
 
     // resident data
     double *d_image = nullptr;       // interleaved {weight sum, packet count} per pixel, fp64
@@ -496,6 +498,22 @@ int upload_blob(nxc_handle *h)
     if (ib) HIPCHK(hipMemcpyAsync(h->d_blob + hb + fb, h->image_part.data(), ib,
                                   hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->have_image) {
+        // the same image tables right behind the header: k_image stages 45 KB instead of 100+, so
+        // that several of its workgroups fit a CU (it was one 256-thread group per CU)
+        LdsHeader hdr = h->header;
+        for (int l = 0; l < h->G.n_lines; l++)
+            hdr.G.line[l] = placed_lut(h->line_local[l], hb + h->line_start[l]);
+        hdr.G.xedges_off = h->xedges_local + (int64_t)hb;
+        hdr.G.zedges_off = h->zedges_local + (int64_t)hb;
+        h->img_bytes = hb + ib;
+        rc = ensure(reinterpret_cast<void **>(&h->d_blob_img), &h->blob_img_cap, h->img_bytes);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_blob_img, &hdr, sizeof(LdsHeader), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_blob_img + hb, h->image_part.data(), ib, hipMemcpyHostToDevice,
+                              h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));      // hdr is a local
+    }
     return NXC_OK;
 }
 
@@ -1023,11 +1041,17 @@ template <typename T>
 int image_run(nxc_handle *h, int64_t p, const T *dx, const T *dy, const T *dz, const T *dvy,
               const T *dfrac)
 {
-    int rc;
-    if ((rc = prep_kernel(k_image<T>, h->all_bytes))) return rc;
+    int rc, per_cu = 0;
+    if ((rc = prep_kernel(k_image<T>, h->img_bytes))) return rc;
+    // as many 1024-thread groups as fit a CU (two for Na's 45 KB of tables), each staging the
+    // tables once and striding over the samples
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image<T>, NXC_IMAGE_BLOCK,
+                                                        h->img_bytes));
+    int64_t grid = (int64_t)h->n_cu * (per_cu > 0 ? per_cu : 1);
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (p + NXC_IMAGE_BLOCK - 1) / NXC_IMAGE_BLOCK));
     if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(k_image<T>, dim3(flat_grid(h, p, NXC_BLOCK)), dim3(NXC_BLOCK), h->all_bytes,
-                       h->stream, h->d_blob, (int64_t)h->all_bytes, p, dx, dy, dz, dvy, dfrac,
+    hipLaunchKernelGGL(k_image<T>, dim3((unsigned)grid), dim3(NXC_IMAGE_BLOCK), h->img_bytes,
+                       h->stream, h->d_blob_img, (int64_t)h->img_bytes, p, dx, dy, dz, dvy, dfrac,
                        h->d_image, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
@@ -1131,7 +1155,8 @@ int nxc_destroy(nxc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
-                    h->d_source, h->d_queue, h->d_samples, h->d_hist, h->d_rec, h->d_piece_hist};
+                    h->d_source, h->d_queue, h->d_samples, h->d_hist, h->d_rec, h->d_piece_hist,
+                    h->d_blob_img};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     pool_flush(h);

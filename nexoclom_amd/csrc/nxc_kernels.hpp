@@ -707,8 +707,9 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
 // ---------------------------------------------------------------------------------------------
 // T = double, or float for samples handed over as the reference stores them (Output.py:528-543);
 // widening a float is exact, so both give the same image.
+constexpr int NXC_IMAGE_BLOCK = 1024;
 template <typename T>
-__global__ void __launch_bounds__(NXC_BLOCK)
+__global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
 k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
         const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z,
         const T *__restrict__ vy, const T *__restrict__ frac,
