@@ -322,7 +322,7 @@ struct nxc_handle {
     size_t packets_cap = 0;
     int64_t n_packets = 0;
     unsigned *d_order = nullptr;     // packet indices by decreasing launch speed (queue order)
-    double *d_queue = nullptr;       // the state columns permuted into that order
+    double *d_queue = nullptr;       // the packets in that order, one 64-byte record each: [n][8]
     size_t queue_cap = 0;
     size_t order_cap = 0;
     bool have_order = false;
@@ -1529,8 +1529,8 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
 }
 
 // Counting sort of `n` packets (columns `stride` apart, starting at `soa`) by decreasing |v|^2, or
-// by decreasing lifetime (d_lifetimes), entirely on `st`: histogram -> device scan -> scatter ->
-// gather into the queue copy out_queue (columns out_stride apart; default n: compact) with
+// by decreasing lifetime (d_lifetimes), entirely on `st`: histogram -> device scan -> scatter of
+// the packets themselves into the queue out_queue[n][8] (one 64-byte record per packet) with
 // out_order[n] = base + local packet index.
 // scale > 0: the bin scale; scale <= 0: taken on the device from *d_max (k_speed_max ran before).
 // beside_persistent: the launches may have to run next to a persistent kernel that fills every
@@ -1538,9 +1538,8 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
 static int order_async(nxc_handle *h, hipStream_t st, const double *soa, int64_t stride, int64_t n,
                        const long long *d_lifetimes, double scale, unsigned long long *d_max,
                        unsigned long long *d_hist, unsigned *out_order, double *out_queue,
-                       bool beside_persistent, unsigned base = 0, int64_t out_stride = 0)
+                       bool beside_persistent, unsigned base = 0)
 {
-    if (out_stride == 0) out_stride = n;
     const size_t hb = (size_t)NXC_ORDER_BINS * sizeof(unsigned long long);
     const int grid = flat_grid(h, n, NXC_BLOCK);
     const unsigned long long *mx = scale > 0 ? (const unsigned long long *)nullptr : d_max;
@@ -1554,13 +1553,9 @@ static int order_async(nxc_handle *h, hipStream_t st, const double *soa, int64_t
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, d_hist);
     HIPCHK(hipGetLastError());
-    if (d_lifetimes) NXC_ORDER_LAUNCH(k_order_scatter<true>, d_hist, out_order, base);
-    else NXC_ORDER_LAUNCH(k_order_scatter<false>, d_hist, out_order, base);
+    if (d_lifetimes) NXC_ORDER_LAUNCH(k_order_scatter<true>, d_hist, out_order, base, out_queue);
+    else NXC_ORDER_LAUNCH(k_order_scatter<false>, d_hist, out_order, base, out_queue);
 #undef NXC_ORDER_LAUNCH
-    HIPCHK(hipGetLastError());
-    // the persistent kernels read the queue front to back: give them a contiguous copy
-    hipLaunchKernelGGL(k_order_gather, dim3(grid), dim3(NXC_BLOCK), 0, st, soa, stride, n,
-                       (const unsigned *)out_order, base, out_queue, out_stride);
     HIPCHK(hipGetLastError());
     return NXC_OK;
 }
@@ -1867,7 +1862,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, len, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
                            h->stream2, (const double *)(h->d_packets + p0), n, len, d_max);
         if ((rc = order_async(h, h->stream2, h->d_packets + p0, n, len, nullptr, 0.0, d_max, hist,
-                              h->d_order + p0, h->d_queue + p0, true, (unsigned)p0, n)))
+                              h->d_order + p0, h->d_queue + 8 * p0, true, (unsigned)p0)))
             return give_up(rc);
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->stream2, d_avail,
                            (unsigned long long)(p0 + len));

@@ -421,6 +421,10 @@ struct LoopK {
     long long n;
     const long long *offsets;     // ROWS pass: row offsets per packet index
     const unsigned long long *avail;   // streamed upload: queue positions published so far (null: all)
+    // layout of soa0: doubles between consecutive queue positions / between a packet's columns.
+    // The ordered queue holds one 64-byte record per packet (8, 1); unordered packets are read
+    // where they were uploaded, as columns (1, n).
+    long long q_rec, q_col;
 };
 // Refined reciprocals of the two launch-constant divisors of the weight (1e6, Apix), computed once
 // per workgroup; read from LDS by the samples that fall inside the image.

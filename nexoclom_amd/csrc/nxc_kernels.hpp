@@ -96,6 +96,7 @@ NXC_DEV void stage_tables_and_args(const unsigned char *__restrict__ blob, int64
         LoopK &L = lds_header_rw().L;
         L.soa0 = soa0; L.order = order; L.final_out = final_out; L.steps_out = steps_out;
         L.head = head; L.n = n; L.offsets = offsets; L.avail = avail;
+        L.q_rec = order ? 8 : 1; L.q_col = order ? 1 : n;
     }
     __syncthreads();
 }
@@ -372,11 +373,12 @@ struct WaveQueue {
                     // header) the compiler must assume that they may alias the staging block and
                     // emits load, wait, store, load, wait, store ... -- nine memory round trips in
                     // a row for every chunk (round 3: seen in the ISA, 3 % of a wave's time).
-                    const NXC_GLOBAL_AS double *g = (const NXC_GLOBAL_AS double *)soa0 + (b + lane);
+                    const long long q_col = L.q_col;
+                    const NXC_GLOBAL_AS double *g = (const NXC_GLOBAL_AS double *)soa0 + (b + lane) * L.q_rec;
                     const NXC_GLOBAL_AS unsigned *gid = (const NXC_GLOBAL_AS unsigned *)ids;
                     double col[8];
 #pragma unroll
-                    for (int c = 0; c < 8; c++) col[c] = g[c * n];
+                    for (int c = 0; c < 8; c++) col[c] = g[c * q_col];
                     const long long pid = gid ? (long long)gid[b + lane] : b + lane;
                     long long o0 = 0, o1 = 0;
                     if (ROWS) {
@@ -1332,33 +1334,30 @@ k_order_scan(unsigned long long *__restrict__ hist)
     }
 }
 
-// The state columns in queue order: out[c * out_stride + q] = soa[c * stride + order[q] - base],
-// q < n (order holds indices into the whole set: the piece's first packet is number `base`).
-__global__ void __launch_bounds__(NXC_BLOCK)
-k_order_gather(const double *__restrict__ soa, int64_t stride, int64_t n,
-               const unsigned *__restrict__ order, unsigned base, double *__restrict__ out,
-               int64_t out_stride)
-{
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n;
-         q += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = order[q] - base;
-#pragma unroll
-        for (int c = 0; c < 8; c++) out[c * out_stride + q] = soa[c * stride + i];
-    }
-}
-
 template <bool BY_STEPS>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
                 int64_t n, double scale_, const unsigned long long *__restrict__ max_bits,
-                unsigned long long *__restrict__ cursor, unsigned *__restrict__ order, unsigned base)
+                unsigned long long *__restrict__ cursor, unsigned *__restrict__ order, unsigned base,
+                double *__restrict__ queue)
 {
+    // Every packet takes the next free position of its bin and goes there whole: the eight columns
+    // are read along the packets (coalesced) and leave as ONE 64-byte record per packet -- the
+    // queue the persistent kernels read front to back.  (Until round 3 the positions were
+    // scattered first and the columns gathered by a second kernel, whose 8-byte reads at random
+    // rows fetched six times the bytes they used.)
     const double scale = order_scale(scale_, max_bits);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = soa[c * stride + i];
         const unsigned long long pos =
             atomicAdd(&cursor[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1ull);
         order[pos] = base + (unsigned)i;
+        nxc_v2d *rec = reinterpret_cast<nxc_v2d *>(queue + 8 * pos);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { nxc_v2d t; t.x = v[2 * c]; t.y = v[2 * c + 1]; rec[c] = t; }
     }
 }
 

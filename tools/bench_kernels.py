@@ -186,7 +186,7 @@ def main():
         up_ms = (time.perf_counter() - t0)*1e3
     print(json.dumps({'kernel': 'nxc_packets_upload', 'call_ms': up_ms, 'packets': soa.shape[1],
                       'note': 'H2D of 64 B/packet from pageable memory + k_speed_max + '
-                              'k_order_hist + k_order_scan + k_order_scatter + k_order_gather'}))
+                              'k_order_hist + k_order_scan + k_order_scatter'}))
 
     # ---- SURVEY 8(d)'s stress vector: no early deaths, so no refill, no empty lanes, no queue
     # order -- the step loop's own rate.  Packets start at rest 30 R from the planet, outside its
