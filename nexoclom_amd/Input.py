@@ -159,49 +159,66 @@ class Input:
             print('Running Model')
             print(f'Will complete {passes} iterations of {size} packets.')
             number = 0
-            while number < passes:
-                tick = time.time()
-                # as many Outputs per launch as HBM takes (rows: nsteps records per packet at most,
-                # far fewer in practice; the row store spills its oldest runs to the host)
-                group = min(passes - number, self._group_limit(size, context)) if together else 1
-                outs = []
-                if together and sampler == 'numpy' and group > 1:
-                    # the Outputs of a group are independent draws (seed + k): sample them on a
-                    # few threads (NumPy releases the GIL in its loops), integrate them together
-                    from concurrent.futures import ThreadPoolExecutor
-                    seeds = [None if seed is None else seed + made + g for g in range(group)]
-                    with ThreadPoolExecutor(max_workers=min(group, HOST_SAMPLER_THREADS)) as pool:
-                        outs = list(pool.map(
-                            lambda s_: Output(self, size, compress=compress, device=device,
-                                              keep_trajectory=keep_trajectory, context=context,
-                                              integrate=False, save=False, seed=s_), seeds))
-                    number += group
-                    drawn += size*group
-                    made += group
-                    group = 0
-                for g in range(group):
-                    number += 1
-                    print(f'Starting iteration #{number} of {passes}')
-                    if sampler == 'device' and generator == 'pcg64':
-                        draw = dict(seed=seed + made, sampler='device', generator='pcg64',
-                                    first_index=drawn, presampled=together,
-                                    materialize_x0=not together)
-                    elif sampler == 'device':
-                        draw = dict(seed=seed, sampler='device', first_index=drawn,
-                                    presampled=together, materialize_x0=not together)
-                    else:
-                        draw = dict(seed=None if seed is None else seed + made)
-                    out = Output(self, size, compress=compress, device=device,
-                                 keep_trajectory=keep_trajectory, context=context,
-                                 integrate=not together, save=not together, **draw)
-                    context = out.context()      # every Output of the run shares one device
-                    outs.append(out)
-                    drawn += size
-                    made += 1
-                if together and outs:
-                    self._launch_group(outs, context, sampler, generator, seed, size,
-                                       first_seed=None if seed is None else seed + made - len(outs))
-                print(f'Completed iteration #{number} in {time.time() - tick} seconds.')
+            ahead = None                         # the next launch group's Outputs, being drawn
+            pool = None
+
+            def draw_ahead(first, count):
+                # the Outputs of a group are independent draws (seed + k): sample them on a few
+                # threads (NumPy releases the GIL in its loops), integrate them together
+                seeds = [None if seed is None else seed + first + g for g in range(count)]
+                return [pool.submit(Output, self, size, compress=compress, device=device,
+                                    keep_trajectory=keep_trajectory, context=context,
+                                    integrate=False, save=False, seed=s_) for s_ in seeds]
+
+            try:
+                while number < passes:
+                    tick = time.time()
+                    # as many Outputs per launch as HBM takes (rows: nsteps records per packet at
+                    # most, far fewer in practice; the row store spills its oldest runs to the host)
+                    limit = self._group_limit(size, context) if together else 1
+                    group = min(passes - number, limit)
+                    outs = []
+                    if together and sampler == 'numpy' and (group > 1 or ahead is not None):
+                        if pool is None:
+                            from concurrent.futures import ThreadPoolExecutor
+                            pool = ThreadPoolExecutor(max_workers=HOST_SAMPLER_THREADS)
+                        futures = ahead if ahead is not None else draw_ahead(made, group)
+                        group = len(futures)
+                        # ... and the group after this one while this one is integrated
+                        later = min(passes - number - group, self._group_limit(size, context))
+                        ahead = draw_ahead(made + group, later) if later > 0 else None
+                        outs = [f.result() for f in futures]
+                        number += group
+                        drawn += size*group
+                        made += group
+                        group = 0
+                    for g in range(group):
+                        number += 1
+                        print(f'Starting iteration #{number} of {passes}')
+                        if sampler == 'device' and generator == 'pcg64':
+                            draw = dict(seed=seed + made, sampler='device', generator='pcg64',
+                                        first_index=drawn, presampled=together,
+                                        materialize_x0=not together)
+                        elif sampler == 'device':
+                            draw = dict(seed=seed, sampler='device', first_index=drawn,
+                                        presampled=together, materialize_x0=not together)
+                        else:
+                            draw = dict(seed=None if seed is None else seed + made)
+                        out = Output(self, size, compress=compress, device=device,
+                                     keep_trajectory=keep_trajectory, context=context,
+                                     integrate=not together, save=not together, **draw)
+                        context = out.context()      # every Output of the run shares one device
+                        outs.append(out)
+                        drawn += size
+                        made += 1
+                    if together and outs:
+                        first = None if seed is None else seed + made - len(outs)
+                        self._launch_group(outs, context, sampler, generator, seed, size,
+                                           first_seed=first)
+                    print(f'Completed iteration #{number} in {time.time() - tick} seconds.')
+            finally:
+                if pool is not None:
+                    pool.shutdown(cancel_futures=True)
             have = self._report()
         self.wait()                              # files of this run are on disk when it returns
         print(f'Model run completed in {time.time() - started:.2f} sec.')
