@@ -945,8 +945,14 @@ struct LosQueue {
 // go through a per-wave LDS queue, so that their samples meet los_pair with full waves;
 // everything else costs one sphere test per 8 pairs.  K.cull = 0 (boresights that are not unit
 // vectors) sends every block through.
+// 512 threads: two workgroups (50 KB of LDS each) = 16 waves per CU; with 256 it was 12, and the
+// kernel -- half culling loop, half candidate drains with dependent global loads -- ran 28 % longer
+// (reading the next spectrum from LDS ahead of the queue's fence: 6 % at 256 threads, nothing at 512)
+#ifndef NXC_LOS_THREADS
+#define NXC_LOS_THREADS 512
+#endif
 template <typename T, typename I>
-__global__ void __launch_bounds__(NXC_BLOCK)
+__global__ void __launch_bounds__(NXC_LOS_THREADS)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
       const double *__restrict__ sc, int64_t P, const T *__restrict__ x,
       const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ vy,
