@@ -350,6 +350,17 @@ int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double
  * with half the host-to-device bytes and no 64-bit copy on the host. */
 int nxc_image_accumulate_f32(nxc_handle *h, int64_t p, const float *x, const float *y,
                              const float *z, const float *vy, const float *frac);
+/* How the image calls above (and nxc_image_accumulate_rows) add their samples to the image:
+ * mode 1 = one global atomic pair per binned sample (k_image); mode 2 = LDS-privatised tiles
+ * (k_image_bin + k_image_tiles: the samples are filed by image tile first, a workgroup sums a tile
+ * in LDS and hands it over once -- the replacement of np.histogram2d's bincount,
+ * math/histogram.py:34, at HBM speed instead of atomic-request speed); mode 0 (default) = tiles for
+ * 2^23 samples and more when the image fits them (up to 32 tiles of 8192 pixels: 512 x 512),
+ * atomics otherwise.  Packet counts are identical either way, weight sums equal to the order of
+ * fp64 additions.  tile_pixels: 0 = 8192; slab_samples: 0 = 2^27, the samples that go through the
+ * two passes at a time (their chunk scratch is 10 bytes per sample at worst); smaller values of
+ * both exist for tests (more tiles on a small image, several slabs of a small sample set). */
+int nxc_image_mode(nxc_handle *h, int mode, int tile_pixels, int64_t slab_samples);
 
 /* ---- f-1: spacecraft line-of-sight cones ----------------------------------------------------------
  * For each of S spectra (spacecraft position + boresight) sum weight/Apix over the stored samples

@@ -337,6 +337,11 @@ struct nxc_handle {
     size_t scratch_cap = 0;
     unsigned char *d_samples = nullptr;   // host sample columns on their way to k_image / k_los
     size_t samples_cap = 0;
+    unsigned char *d_tiles = nullptr;     // chunk scratch of the tiled image (k_image_bin -> k_image_tiles)
+    size_t tiles_cap = 0;
+    int image_mode = 0;                   // nxc_image_mode: 0 by size, 1 k_image, 2 tiles
+    int tile_pixels = NXC_TILE_PIXELS;
+    int64_t tile_slab = int64_t(1) << 27; // samples per pass of the tiled image (bounds its scratch)
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
     unsigned long long *d_hist = nullptr;   // counting-sort bins of the queue order
@@ -1036,12 +1041,100 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
                                  0, n_index, radiance, npackets, included, used_cap, used_pairs, n_used);
 }
 
+// Geometry of the tiled image: tile b = image rows ix = b (mod nb), nb a power of two; a tile's
+// pixels (ix / nb, iz) must fit the LDS tile.  False when the image has too many pixels for
+// NXC_TILE_MAX tiles (1024^2 and up): such images stay with k_image.
+struct TilePlan {
+    int nb_log2 = 0, tile_used = 0;
+    size_t lds_bin = 0;
+};
+bool tile_plan(const nxc_handle *h, TilePlan *out)
+{
+    const int nx = h->header.G.nx, nz = h->header.G.nz;
+    if (nx < 1 || nz < 1 || nz > h->tile_pixels) return false;
+    const int rows = h->tile_pixels / nz;                    // image rows per tile
+    int lg = 0;
+    while (((nx + (1 << lg) - 1) >> lg) > rows) lg++;
+    if ((1 << lg) > NXC_TILE_MAX) return false;
+    out->nb_log2 = lg;
+    out->tile_used = ((nx + (1 << lg) - 1) >> lg) * nz;
+    out->lds_bin = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)(1 << lg) * NXC_TILE_CHUNK * 10 +
+                   ((size_t)(1 << lg) + 3) * 4;
+    return out->lds_bin <= 160 * 1024;
+}
+
+// a-6..a-8 over samples on the device, through LDS-privatised tiles (nxc_kernels.hpp: k_image_bin,
+// k_image_tiles).  The samples go through in slabs so that the chunk scratch stays bounded
+// (10 bytes per sample of a slab at worst: every sample inside the image).
+template <typename T, bool DEFER>
+int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, const T *dy,
+                    const T *dz, const T *dvy, const T *dfrac)
+{
+    int rc, per_cu = 0;
+    // pass 2 forms the weights (DEFER): the image tables sit in front of its tile
+    const size_t tables = DEFER ? (h->img_bytes + 15) & ~size_t(15) : 0;
+    const size_t lds_tiles = tables + (size_t)NXC_TILE_PIXELS * 12;
+    if ((rc = prep_kernel(k_image_bin<T, DEFER>, tp.lds_bin))) return rc;
+    if ((rc = prep_kernel(k_image_tiles<DEFER>, lds_tiles))) return rc;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image_bin<T, DEFER>,
+                                                        NXC_IMAGE_BLOCK, tp.lds_bin));
+    const int nb = 1 << tp.nb_log2;
+    const int64_t per_trip = (int64_t)NXC_IMAGE_BLOCK * NXC_TILE_UNROLL;
+    const int64_t slab = std::min<int64_t>(p, h->tile_slab);
+    int64_t prod = (int64_t)h->n_cu * (per_cu > 0 ? per_cu : 1);
+    prod = std::max<int64_t>(1, std::min<int64_t>(prod, (slab + per_trip - 1) / per_trip));
+    const int64_t span = ((slab + prod - 1) / prod + per_trip - 1) / per_trip * per_trip;
+    const int64_t mc = span / NXC_TILE_CHUNK + nb;
+    const int ng = std::max(1, h->n_cu / nb);             // consumer groups per tile
+    // scratch: payloads | pixels-in-tile | chunk tags | chunks per producer
+    const size_t entries = (size_t)prod * (size_t)mc * NXC_TILE_CHUNK;
+    const size_t o_sl = entries * 8, o_tag = o_sl + entries * 2;
+    const size_t o_n = (o_tag + (size_t)prod * (size_t)mc * 2 + 255) & ~size_t(255);
+    if ((rc = ensure(reinterpret_cast<void **>(&h->d_tiles), &h->tiles_cap, o_n + (size_t)prod * 4)))
+        return rc;
+    double *sw = reinterpret_cast<double *>(h->d_tiles);
+    unsigned short *sl = reinterpret_cast<unsigned short *>(h->d_tiles + o_sl);
+    unsigned short *tag = reinterpret_cast<unsigned short *>(h->d_tiles + o_tag);
+    unsigned *nchunks = reinterpret_cast<unsigned *>(h->d_tiles + o_n);
+    if ((rc = begin_timed(h))) return rc;
+    for (int64_t first = 0; first < p; first += slab) {
+        const int64_t n = std::min<int64_t>(slab, p - first);
+        const int64_t grid = (n + span - 1) / span;       // <= prod; the scratch regions keep their place
+        hipLaunchKernelGGL((k_image_bin<T, DEFER>), dim3((unsigned)grid), dim3(NXC_IMAGE_BLOCK),
+                           tp.lds_bin, h->stream, h->d_blob_img, (int64_t)h->img_bytes, n, span,
+                           (int)mc, tp.nb_log2, dx + first, dy + first, dz + first, dvy + first,
+                           dfrac + first, sw, sl, tag, nchunks, h->d_ctr);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_image_tiles<DEFER>, dim3((unsigned)(nb * ng)), dim3(NXC_IMAGE_BLOCK),
+                           lds_tiles, h->stream, h->d_blob_img, (int64_t)h->img_bytes, (int)grid,
+                           (int)mc, tp.nb_log2, ng, tp.tile_used, (int)h->header.G.nz, sw, sl, tag,
+                           nchunks, h->d_image, h->d_ctr);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = end_timed(h))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return NXC_OK;
+}
+
 // a-6..a-8 over samples on the device
+constexpr int64_t NXC_TILE_MIN_SAMPLES = int64_t(1) << 23;   // below this the two launches do not pay
 template <typename T>
 int image_run(nxc_handle *h, int64_t p, const T *dx, const T *dy, const T *dz, const T *dvy,
               const T *dfrac)
 {
     int rc, per_cu = 0;
+    TilePlan tp;
+    const bool fits = tile_plan(h, &tp);
+    if (h->image_mode == 2 && !fits)
+        return fail(NXC_ERR_ARG, "this image does not fit the tiled path (too many pixels)");
+    if (fits && (h->image_mode == 2 || (h->image_mode == 0 && p >= NXC_TILE_MIN_SAMPLES))) {
+        // float32 samples (stored rows, the down-cast image) leave the weight to pass 2 when the
+        // image tables fit a CU's LDS next to a tile
+        const bool f32_values = sizeof(T) == 4 || h->header.G.downcast_f32 != 0;
+        const bool room = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)NXC_TILE_PIXELS * 12 <= 160 * 1024;
+        if (f32_values && room) return image_run_tiles<T, true>(h, tp, p, dx, dy, dz, dvy, dfrac);
+        return image_run_tiles<T, false>(h, tp, p, dx, dy, dz, dvy, dfrac);
+    }
     if ((rc = prep_kernel(k_image<T>, h->img_bytes))) return rc;
     // as many 1024-thread groups as fit a CU (two for Na's 45 KB of tables), each staging the
     // tables once and striding over the samples
@@ -1155,7 +1248,7 @@ int nxc_destroy(nxc_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
-                    h->d_source, h->d_queue, h->d_samples, h->d_hist, h->d_rec, h->d_piece_hist,
+                    h->d_source, h->d_queue, h->d_samples, h->d_tiles, h->d_hist, h->d_rec, h->d_piece_hist,
                     h->d_blob_img};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1403,6 +1496,22 @@ int nxc_image_clear(nxc_handle *h)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemsetAsync(h->d_image, 0, 2 * h->npix * sizeof(double), h->stream));
     return NXC_OK;
+}
+
+int nxc_image_mode(nxc_handle *h, int mode, int tile_pixels, int64_t slab_samples)
+{
+    return guarded([&]() -> int {
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    if (mode < 0 || mode > 2) return fail(NXC_ERR_ARG, "mode is 0 (by size), 1 (atomics) or 2 (tiles)");
+    if (tile_pixels < 0 || tile_pixels > NXC_TILE_PIXELS)
+        return fail(NXC_ERR_ARG, "tile_pixels is 0 (default) or at most 8192");
+    if (slab_samples < 0 || slab_samples > (int64_t(1) << 31))
+        return fail(NXC_ERR_ARG, "slab_samples is 0 (default) or at most 2^31");
+    h->image_mode = mode;
+    h->tile_pixels = tile_pixels ? tile_pixels : NXC_TILE_PIXELS;
+    h->tile_slab = slab_samples ? slab_samples : int64_t(1) << 27;
+    return NXC_OK;
+    });
 }
 
 int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)

@@ -795,9 +795,10 @@ NXC_DEV void image_add_pairs(bool has, int pix, double w, double *__restrict__ a
 //   image_weight: weight of a located sample (ModelResult.py:148-161, ModelImage.py:262); false
 //                 when it is not finite (the reference asserts, ModelResult.py:170; here the
 //                 sample is counted in `nonfinite` and never reaches a pixel).
-NXC_DEV int image_locate_core(const ImageK &G, const ImageRegs &R, double x, double y, double z,
-                              double vy, double frac, double &radvel_out, double &fw_out,
-                              unsigned long long &nonfinite)
+// (ix, iz as two numbers for the tiled image, which files a sample under its row's tile)
+NXC_DEV bool image_locate_core_xz(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                                  double vy, double frac, double &radvel_out, double &fw_out,
+                                  unsigned long long &nonfinite, int &ix_out, int &iz_out)
 {
     const double radvel = vy + R.vrplanet;                         // ModelImage.py:242-243
     double xo, yo, zo;                                             // ModelImage.py:249
@@ -817,7 +818,7 @@ NXC_DEV int image_locate_core(const ImageK &G, const ImageRegs &R, double x, dou
     if (ix < 0 || iz < 0) {
         // outside the image the weight is not formed; it is finite iff frac and radvel are
         if (!(__builtin_fabs(frac) <= 1.7976931348623157e308) || radvel != radvel) nonfinite++;
-        return -1;
+        return false;
     }
     const double s_obs = xo * xo + zo * zo;                        // ModelImage.py:252-254
     const bool inview = (s_obs > 0x1.0000000000001p+0) || (yo < 0.0);
@@ -826,6 +827,17 @@ NXC_DEV int image_locate_core(const ImageK &G, const ImageRegs &R, double x, dou
         frac = sunlit(x, y, z) ? frac : frac * 0.0;                //   * out_of_shadow
     radvel_out = radvel;
     fw_out = frac;
+    ix_out = ix; iz_out = iz;
+    return true;
+}
+
+NXC_DEV int image_locate_core(const ImageK &G, const ImageRegs &R, double x, double y, double z,
+                              double vy, double frac, double &radvel_out, double &fw_out,
+                              unsigned long long &nonfinite)
+{
+    int ix = 0, iz = 0;
+    if (!image_locate_core_xz(G, R, x, y, z, vy, frac, radvel_out, fw_out, nonfinite, ix, iz))
+        return -1;
     return ix * R.nz + iz;
 }
 

@@ -735,6 +735,276 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same image through LDS-privatised tiles (the histogram design BASELINE.json names), for
+// sample sets large enough to pay for two launches.  k_image is bound by the chip's memory-side
+// atomic request rate (2.1-2.4e10/s: one request per binned sample, whatever the pixel), a fifth of
+// what HBM could stream; the samples of a cloud have no pixel locality a wave could merge on, so
+// locality is MADE: pass 1 (k_image_bin) locates and weighs every sample as k_image does and
+// appends the binned ones -- {weight fp64, pixel-in-tile u16} -- to the staging block of the
+// sample's TILE in LDS; a full block of 256 leaves for HBM as one chunk (2.5 KB of contiguous
+// stores) in the workgroup's own scratch region, so no global atomic is involved.  Pass 2
+// (k_image_tiles): a workgroup owns one tile as 8192 x {fp64 sum, u32 count} in LDS, adds the
+// chunks tagged with its tile by LDS atomics (ds_add_f64 / ds_add_u32), and hands the tile to the
+// resident image with one pair of global atomics per touched pixel.  Tile b holds the image rows
+// ix = b (mod nb): every tile sees the same cut through the cloud, so the static assignment of
+// tiles to workgroups is balanced.  Packet counts are exact as before; the weight sums differ from
+// k_image's by the order of fp64 additions only (both are unordered).
+constexpr int NXC_TILE_CHUNK = 256;         // entries per chunk
+constexpr int NXC_TILE_MAX = 32;            // tiles per image at most
+constexpr int NXC_TILE_PIXELS = 8192;       // pixels per tile at most (96 KB of LDS)
+constexpr int NXC_TILE_UNROLL = 2;          // samples per thread between two workgroup barriers
+
+// Workgroup barrier that orders LDS traffic only: the global loads of the next samples stay in
+// flight across it (__syncthreads waits for vmcnt(0) as well).
+NXC_DEV void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// image_add_pairs for a pixel that carries a whole count (pass 2's hand-over).
+NXC_DEV void image_add_pairs_n(bool has, int pix, double w, double cnt, double *__restrict__ acc2)
+{
+    if (__ballot(has) == 0) return;
+    const bool upper = (threadIdx.x & 32) != 0;
+    const int ppix = half_swap(has ? pix : -1, upper);
+    const auto pc = __builtin_amdgcn_permlane32_swap(__double2loint(cnt), __double2loint(cnt), false, false);
+    const auto ph = __builtin_amdgcn_permlane32_swap(__double2hiint(cnt), __double2hiint(cnt), false, false);
+    const double pcnt = __hiloint2double(upper ? (int)ph[0] : (int)ph[1], upper ? (int)pc[0] : (int)pc[1]);
+    const bool own = has && w != 0.0;
+    const bool partner = ppix >= 0;
+    {
+        const bool act = upper ? partner : own;
+        if (act)
+            unsafeAtomicAdd(&acc2[2ll * (upper ? ppix : pix) + (upper ? 1 : 0)], upper ? pcnt : w);
+    }
+    {
+        const bool act = upper ? own : partner;
+        if (act)
+            unsafeAtomicAdd(&acc2[2ll * (upper ? pix : ppix) + (upper ? 0 : 1)], upper ? w : pcnt);
+    }
+}
+
+// Pass 1.  Workgroup k takes the samples [k span, (k + 1) span) and owns the chunks
+// [k mc, (k + 1) mc) of the scratch arrays: sw / sl hold a chunk's 8-byte payloads / pixels-in-tile,
+// tag[c] = tile << 8 | (entries - 1), nchunks[k] the chunks it wrote (at most span / 256 full ones
+// + one partial per tile = mc).
+// DEFER: the payload is {vy, masked frac} as two floats and pass 2 forms the weight -- on full
+// waves of binned samples, where this pass would run the g-value lookups and divisions with the
+// half of its lanes whose sample fell inside the image; possible whenever the samples are float32
+// values (stored rows, or the down-cast image), since the masked fraction is frac or a zero.
+// Otherwise the payload is the fp64 weight itself.
+template <typename T, bool DEFER>
+__global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
+k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p, int64_t span,
+            int mc, int nb_log2, const T *__restrict__ x, const T *__restrict__ y,
+            const T *__restrict__ z, const T *__restrict__ vy, const T *__restrict__ frac,
+            double *__restrict__ sw, unsigned short *__restrict__ sl,
+            unsigned short *__restrict__ tag, unsigned *__restrict__ nchunks,
+            DevCounters *__restrict__ ctr)
+{
+    constexpr int CAP = NXC_TILE_CHUNK, U = NXC_TILE_UNROLL;
+    stage_tables(blob, stage_bytes);
+    const ImageRegs IR = image_regs(lds_header().G);
+    const int nb = 1 << nb_log2;
+    const int s0 = ((int)stage_bytes + 15) & ~15;
+    double *const stw = reinterpret_cast<double *>(nxc_lds + s0);                        // [nb][CAP]
+    unsigned short *const stl = reinterpret_cast<unsigned short *>(nxc_lds + s0 + nb * CAP * 8);
+    unsigned *const cnt = reinterpret_cast<unsigned *>(nxc_lds + s0 + nb * CAP * 10);    // [nb]
+    unsigned *const nch = cnt + nb;                   // chunks written so far
+    unsigned *const again = nch + 1;                  // [2]: somebody still holds an entry
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
+    if (tid < nb + 3) cnt[tid] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * span;
+    const int64_t hi = lo + span < p ? lo + span : p;
+    const size_t chunk0 = (size_t)blockIdx.x * (size_t)mc;
+
+    // a wave moves staging block b (n entries) to the workgroup's next chunk
+    auto flush = [&](int b, int n) {
+        unsigned j = 0;
+        if (lane == 0) j = atomicAdd(nch, 1u);
+        j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+        const size_t c = (chunk0 + j) * CAP;
+#pragma unroll
+        for (int t = 0; t < CAP / 64; t++) {
+            const int e = lane + 64 * t;
+            if (e < n) { sw[c + e] = stw[b * CAP + e]; sl[c + e] = stl[b * CAP + e]; }
+        }
+        if (lane == 0) tag[chunk0 + j] = (unsigned short)((b << 8) | (n - 1));
+    };
+
+    unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
+    unsigned round = 0;
+    // the samples of the first trip; every trip loads the next one's before it works on its own
+    T nx_[U][5];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t i = lo + (int64_t)u * blockDim.x + tid;
+#pragma unroll
+        for (int c = 0; c < 5; c++) nx_[u][c] = T(0);
+        if (i < hi) { nx_[u][0] = x[i]; nx_[u][1] = y[i]; nx_[u][2] = z[i]; nx_[u][3] = vy[i]; nx_[u][4] = frac[i]; }
+    }
+    for (int64_t base = lo; base < hi; base += (int64_t)U * blockDim.x) {    // block-uniform trips
+        T cur[U][5];
+        bool has[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            has[u] = base + (int64_t)u * blockDim.x + tid < hi;
+#pragma unroll
+            for (int c = 0; c < 5; c++) cur[u][c] = nx_[u][c];
+            const int64_t i = base + (int64_t)(U + u) * blockDim.x + tid;
+            if (i < hi) { nx_[u][0] = x[i]; nx_[u][1] = y[i]; nx_[u][2] = z[i]; nx_[u][3] = vy[i]; nx_[u][4] = frac[i]; }
+        }
+        int bk[U], loc[U];
+        double w[U];
+        unsigned pend = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            my_samples += has[u];
+            int ix = 0, iz = 0;
+            double radvel = 0.0, fw = 0.0;
+            double s[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) s[c] = (double)cur[u][c];
+            if (sizeof(T) == 8 && IR.downcast) {        // a widened float is its own round trip
+#pragma unroll
+                for (int c = 0; c < 5; c++) s[c] = f32_round_trip(s[c]);
+            }
+            bool ok = has[u] && image_locate_core_xz(lds_header().G, IR, s[0], s[1], s[2], s[3], s[4],
+                                                     radvel, fw, my_nonfinite, ix, iz);
+            if (DEFER) {
+                w[u] = __hiloint2double(__float_as_int((float)fw), __float_as_int((float)s[3]));
+            } else {
+                w[u] = 0.0;
+                if (ok && !image_weight(lds_header().G, IR, radvel, fw, w[u])) { my_nonfinite++; ok = false; }
+                my_binned += ok;
+            }
+            bk[u] = ix & (nb - 1);
+            loc[u] = (ix >> nb_log2) * IR.nz + iz;
+            pend |= ok ? 1u << u : 0u;
+        }
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (pend >> u & 1u) {
+                    const unsigned pos = atomicAdd(&cnt[bk[u]], 1u);
+                    if (pos < (unsigned)CAP) {
+                        stw[bk[u] * CAP + pos] = w[u];
+                        stl[bk[u] * CAP + pos] = (unsigned short)loc[u];
+                        pend &= ~(1u << u);
+                    }
+                }
+            lds_barrier();
+            if (tid == 0) again[(round + 1) & 1] = 0;
+            for (int b = wid; b < nb; b += nwaves)
+                if (cnt[b] >= (unsigned)CAP) {                     // full (later arrivals try again)
+                    flush(b, CAP);
+                    if (lane == 0) cnt[b] = 0;
+                }
+            if (__ballot(pend != 0) != 0 && lane == 0) again[round & 1] = 1;
+            lds_barrier();
+            const bool more = again[round & 1] != 0;
+            round++;
+            if (!more) break;
+        }
+    }
+    for (int b = wid; b < nb; b += nwaves) {
+        const int n = (int)cnt[b];
+        if (n > 0) flush(b, n);
+    }
+    lds_barrier();
+    if (tid == 0) nchunks[blockIdx.x] = *nch;
+    flush_counter(&ctr->samples, my_samples);
+    flush_counter(&ctr->samples_binned, my_binned);
+    flush_counter(&ctr->nonfinite, my_nonfinite);
+}
+
+// Pass 2.  Workgroup (tile b, group g) adds the chunks of tile b written by the producers
+// k = g (mod ng) into its LDS tile and hands the touched pixels to the resident image.  WEIGH: the
+// chunks hold {vy, masked frac} (k_image_bin<DEFER>) and the weight is formed here, so the image
+// tables are staged in front of the tile.
+template <bool WEIGH>
+__global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
+k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n_prod, int mc,
+              int nb_log2, int ng, int tile_used, int nz,
+              const double *__restrict__ sw, const unsigned short *__restrict__ sl,
+              const unsigned short *__restrict__ tag, const unsigned *__restrict__ nchunks,
+              double *__restrict__ acc2, DevCounters *__restrict__ ctr)
+{
+    constexpr int CAP = NXC_TILE_CHUNK;
+    int t0 = 0;
+    ImageRegs IR = {};
+    if (WEIGH) {
+        stage_tables(blob, stage_bytes);
+        IR = image_regs(lds_header().G);
+        t0 = ((int)stage_bytes + 15) & ~15;
+    }
+    double *const tw = reinterpret_cast<double *>(nxc_lds + t0);
+    unsigned *const tc = reinterpret_cast<unsigned *>(nxc_lds + t0 + 8 * NXC_TILE_PIXELS);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x & ((1 << nb_log2) - 1), g = blockIdx.x >> nb_log2;
+    for (int i = tid; i < tile_used; i += blockDim.x) { tw[i] = 0.0; tc[i] = 0u; }
+    __syncthreads();
+    unsigned long long my_binned = 0, my_nonfinite = 0;
+    for (int k = g; k < n_prod; k += ng) {
+        const unsigned nck = nchunks[k];
+        const size_t c0 = (size_t)k * (size_t)mc;
+        for (unsigned j0 = (unsigned)wid * 64u; j0 < nck; j0 += (unsigned)nwaves * 64u) {
+            const unsigned j = j0 + lane;
+            const unsigned tg = j < nck ? tag[c0 + j] : 0xffffu;
+            unsigned long long m = __ballot(j < nck && (int)(tg >> 8) == b);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int n = (__shfl((int)tg, l, 64) & 255) + 1;
+                const size_t c = (c0 + j0 + l) * CAP;
+                double pay[CAP / 64];
+                int loc[CAP / 64];
+#pragma unroll
+                for (int t = 0; t < CAP / 64; t++) {
+                    const int e = lane + 64 * t;
+                    pay[t] = 0.0; loc[t] = 0;
+                    if (e < n) { pay[t] = sw[c + e]; loc[t] = sl[c + e]; }
+                }
+#pragma unroll
+                for (int t = 0; t < CAP / 64; t++) {
+                    const int e = lane + 64 * t;
+                    if (e < n) {
+                        double w = pay[t];
+                        bool ok = true;
+                        if (WEIGH) {
+                            const double vy = (double)__int_as_float(__double2loint(pay[t]));
+                            const double fw = (double)__int_as_float(__double2hiint(pay[t]));
+                            ok = image_weight(lds_header().G, IR, vy + IR.vrplanet, fw, w);
+                            my_binned += ok;
+                            my_nonfinite += !ok;
+                        }
+                        if (ok) {
+                            if (w != 0.0) unsafeAtomicAdd(&tw[loc[t]], w);
+                            atomicAdd(&tc[loc[t]], 1u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < tile_used; i0 += blockDim.x) {           // block-uniform: pairs cooperate
+        const int i = i0 + tid;
+        const bool has = i < tile_used && tc[i] > 0u;
+        const int lrow = i / nz, iz = i - lrow * nz;
+        const int pix = ((lrow << nb_log2) + b) * nz + iz;
+        image_add_pairs_n(has, pix, has ? tw[i] : 0.0, has ? (double)tc[i] : 0.0, acc2);
+    }
+    if (WEIGH) {
+        flush_counter(&ctr->samples_binned, my_binned);
+        flush_counter(&ctr->nonfinite, my_nonfinite);
+    }
+}
+
 // ---- measurement helpers (bench.py's roofline object) --------------------------------------------
 // Streaming copy, 16 bytes per lane: the box's own HBM ceiling next to the 8 TB/s of the data sheet.
 __global__ void __launch_bounds__(NXC_BLOCK)

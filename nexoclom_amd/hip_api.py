@@ -33,7 +33,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
            'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info',
            'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms',
-           'nxc_integrate_const_streamed')
+           'nxc_integrate_const_streamed', 'nxc_image_mode')
 ABI_VERSION = 2
 
 
@@ -527,6 +527,16 @@ class Context:
         x, y, z, vy, frac = map(_f64, cols)
         self._check(self.lib.nxc_image_accumulate(self._h, C.c_int64(len(x)), _p(x), _p(y), _p(z),
                                                   _p(vy), _p(frac)))
+
+    IMAGE_MODES = {'auto': 0, 'atomics': 1, 'tiles': 2}
+
+    def image_mode(self, mode='auto', tile_pixels=0, slab_samples=0):
+        """How stored samples reach the image: 'atomics' (one global atomic pair per binned
+        sample), 'tiles' (filed by image tile, summed in LDS, handed over once per pixel), or
+        'auto' (tiles from 2^23 samples on).  Packet counts are identical either way."""
+        self._check(self.lib.nxc_image_mode(self._h, C.c_int(self.IMAGE_MODES.get(mode, mode)),
+                                            C.c_int(int(tile_pixels)),
+                                            C.c_int64(int(slab_samples))))
 
     def image_accumulate_rows(self, store, first=0, count=None):
         """Bin rows [first, first + count) of a RowStore: no host round trip."""
