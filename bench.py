@@ -216,6 +216,46 @@ def variable_leg(ctx, inputs_var, n, passes=3):
                          'peak': HBM_PEAK_GBS, 'achieved': ach, 'frac': ach/HBM_PEAK_GBS}}
 
 
+def stored_samples_leg(ctx, inputs, img, aplanet, vrplanet, quantity, n=1_000_000):
+    """a-6..a-8 over STORED samples (the reference's two-stage flow, ModelImage.py:229-274): the
+    float32 rows of n packets stay in HBM (what Input.run leaves there) and are binned by k_image
+    (one global atomic pair per binned sample) and by the tiled image (k_image_bin +
+    k_image_tiles); kernel time by HIP events, 40 / 32 algorithmic bytes per sample."""
+    from nexoclom_amd import Output
+    from nexoclom_amd.Output import n_output_steps
+    opt = inputs.options
+    _, n_iter = n_output_steps(opt.endtime.value, opt.step_size)
+    with quiet():
+        out = Output(inputs, n, seed=SEED, integrate=False, save=False, context=ctx)
+    ctx.set_forces(**out.forces_kwargs())
+    ctx.upload_soa(out.x0_soa())
+    store = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge, narrow=True,
+                                     resident=True)['store']
+    img._set_image(ctx, aplanet, vrplanet, False)
+    per_sample = 40 if quantity == 'radiance' else 32
+    leg = {'samples': int(store.total), 'quantity': quantity,
+           'algorithmic_bytes_per_sample': per_sample}
+    for mode in ('atomics', 'tiles'):
+        ctx.image_mode(mode)
+        ms = []
+        for it in range(4):
+            ctx.image_clear()
+            ctx.image_accumulate_rows(store)
+            if it:
+                ms.append(ctx.last_kernel_ms())
+        k_ms = float(np.mean(ms))
+        ach = per_sample*store.total/(k_ms*1e-3)/1e9
+        leg[mode] = {'kernel': 'k_image' if mode == 'atomics' else 'k_image_bin + k_image_tiles',
+                     'kernel_ms': k_ms, 'samples_per_s': store.total/(k_ms*1e-3),
+                     'binned': ctx.counters()['samples_binned'],
+                     'roofline': {'bound': 'atomic requests' if mode == 'atomics' else 'hbm',
+                                  'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
+                                  'frac': ach/HBM_PEAK_GBS}}
+    ctx.image_mode('auto')
+    store.free()
+    return leg
+
+
 def fail_line(args, world, reason):
     return {'metric': 'particle*steps/s', 'value': None, 'unit': 'particle*steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None,
@@ -453,6 +493,9 @@ def run_rank(args, cp, make_context, emit=print):
             line['other_quantity'] = {'quantity': other, 'kernel_ms': float(np.mean(ms2)),
                                       'value': ctr['particle_steps']/(float(np.mean(ms2))*1e-3),
                                       'unit': 'particle*steps/s'}
+            # a-6..a-8 over stored samples: the reference's two-stage flow (Input.produce_image)
+            line['stored_samples_image'] = stored_samples_leg(ctx, inputs, img, aplanet, vrplanet,
+                                                              args.quantity)
             # the adaptive-step driver (a-4), for the record: at the reference's chunk of 1e6
             # packets (Input.py:218) and at 1e7, which is what Input.run launches at once
             line['variable_step'] = variable_leg(ctx, inputs_var, 1_000_000)

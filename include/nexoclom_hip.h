@@ -357,7 +357,7 @@ int nxc_image_accumulate_f32(nxc_handle *h, int64_t p, const float *x, const flo
  * math/histogram.py:34, at HBM speed instead of atomic-request speed); mode 0 (default) = tiles for
  * 2^23 samples and more when the image fits them (up to 32 tiles of 8192 pixels: 512 x 512),
  * atomics otherwise.  Packet counts are identical either way, weight sums equal to the order of
- * fp64 additions.  tile_pixels: 0 = 8192; slab_samples: 0 = 2^27, the samples that go through the
+ * fp64 additions.  tile_pixels: 0 = 8192; slab_samples: 0 = 2^28, the samples that go through the
  * two passes at a time (their chunk scratch is 10 bytes per sample at worst); smaller values of
  * both exist for tests (more tiles on a small image, several slabs of a small sample set). */
 int nxc_image_mode(nxc_handle *h, int mode, int tile_pixels, int64_t slab_samples);

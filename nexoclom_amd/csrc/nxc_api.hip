@@ -341,7 +341,7 @@ struct nxc_handle {
     size_t tiles_cap = 0;
     int image_mode = 0;                   // nxc_image_mode: 0 by size, 1 k_image, 2 tiles
     int tile_pixels = NXC_TILE_PIXELS;
-    int64_t tile_slab = int64_t(1) << 27; // samples per pass of the tiled image (bounds its scratch)
+    int64_t tile_slab = int64_t(1) << 28; // samples per pass of the tiled image (bounds its scratch)
     long long *d_steps = nullptr;
     size_t steps_cap = 0;
     unsigned long long *d_hist = nullptr;   // counting-sort bins of the queue order
@@ -1059,7 +1059,7 @@ bool tile_plan(const nxc_handle *h, TilePlan *out)
     out->nb_log2 = lg;
     out->tile_used = ((nx + (1 << lg) - 1) >> lg) * nz;
     out->lds_bin = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)(1 << lg) * NXC_TILE_CHUNK * 10 +
-                   ((size_t)(1 << lg) + 3) * 4;
+                   (2 * (size_t)(1 << lg) + 3) * 4;
     return out->lds_bin <= 160 * 1024;
 }
 
@@ -1080,22 +1080,36 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
                                                         NXC_IMAGE_BLOCK, tp.lds_bin));
     const int nb = 1 << tp.nb_log2;
     const int64_t per_trip = (int64_t)NXC_IMAGE_BLOCK * NXC_TILE_UNROLL;
-    const int64_t slab = std::min<int64_t>(p, h->tile_slab);
-    int64_t prod = (int64_t)h->n_cu * (per_cu > 0 ? per_cu : 1);
-    prod = std::max<int64_t>(1, std::min<int64_t>(prod, (slab + per_trip - 1) / per_trip));
-    const int64_t span = ((slab + prod - 1) / prod + per_trip - 1) / per_trip * per_trip;
-    const int64_t mc = span / NXC_TILE_CHUNK + nb;
     const int ng = std::max(1, h->n_cu / nb);             // consumer groups per tile
-    // scratch: payloads | pixels-in-tile | chunk tags | chunks per producer
-    const size_t entries = (size_t)prod * (size_t)mc * NXC_TILE_CHUNK;
-    const size_t o_sl = entries * 8, o_tag = o_sl + entries * 2;
-    const size_t o_n = (o_tag + (size_t)prod * (size_t)mc * 2 + 255) & ~size_t(255);
-    if ((rc = ensure(reinterpret_cast<void **>(&h->d_tiles), &h->tiles_cap, o_n + (size_t)prod * 4)))
-        return rc;
+    int64_t slab_max = std::min<int64_t>(p, h->tile_slab), slab, prod, span, mc;
+    size_t o_sl, o_list, o_n;
+    for (;;) {
+        // slabs of equal size: a short last one would run on a fraction of the chip
+        const int64_t n_slabs = (p + slab_max - 1) / slab_max;
+        slab = (p + n_slabs - 1) / n_slabs;
+        prod = (int64_t)h->n_cu * (per_cu > 0 ? per_cu : 1);
+        prod = std::max<int64_t>(1, std::min<int64_t>(prod, (slab + per_trip - 1) / per_trip));
+        span = ((slab + prod - 1) / prod + per_trip - 1) / per_trip * per_trip;
+        if (span > (int64_t(1) << 23)) {                  // a producer's chunk numbers are 16 bits
+            slab_max = (int64_t(1) << 23) * prod;
+            continue;
+        }
+        mc = span / NXC_TILE_CHUNK + nb;
+        // scratch: payloads | pixels-in-tile | chunk lists [producer][tile][mc] | their lengths
+        const size_t entries = (size_t)prod * (size_t)mc * NXC_TILE_CHUNK;
+        o_sl = entries * 8;
+        o_list = o_sl + entries * 2;
+        o_n = (o_list + (size_t)prod * nb * (size_t)mc * 2 + 255) & ~size_t(255);
+        rc = ensure(reinterpret_cast<void **>(&h->d_tiles), &h->tiles_cap, o_n + (size_t)prod * nb * 4);
+        if (rc == NXC_OK) break;
+        if (slab <= (int64_t(1) << 22)) return rc;        // HBM is full: not even 50 MB
+        (void)hipGetLastError();
+        slab_max = slab >> 1;                             // a smaller slab needs less scratch
+    }
     double *sw = reinterpret_cast<double *>(h->d_tiles);
     unsigned short *sl = reinterpret_cast<unsigned short *>(h->d_tiles + o_sl);
-    unsigned short *tag = reinterpret_cast<unsigned short *>(h->d_tiles + o_tag);
-    unsigned *nchunks = reinterpret_cast<unsigned *>(h->d_tiles + o_n);
+    unsigned short *list = reinterpret_cast<unsigned short *>(h->d_tiles + o_list);
+    unsigned *nlist = reinterpret_cast<unsigned *>(h->d_tiles + o_n);
     if ((rc = begin_timed(h))) return rc;
     for (int64_t first = 0; first < p; first += slab) {
         const int64_t n = std::min<int64_t>(slab, p - first);
@@ -1103,12 +1117,12 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
         hipLaunchKernelGGL((k_image_bin<T, DEFER>), dim3((unsigned)grid), dim3(NXC_IMAGE_BLOCK),
                            tp.lds_bin, h->stream, h->d_blob_img, (int64_t)h->img_bytes, n, span,
                            (int)mc, tp.nb_log2, dx + first, dy + first, dz + first, dvy + first,
-                           dfrac + first, sw, sl, tag, nchunks, h->d_ctr);
+                           dfrac + first, sw, sl, list, nlist, h->d_ctr);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(k_image_tiles<DEFER>, dim3((unsigned)(nb * ng)), dim3(NXC_IMAGE_BLOCK),
                            lds_tiles, h->stream, h->d_blob_img, (int64_t)h->img_bytes, (int)grid,
-                           (int)mc, tp.nb_log2, ng, tp.tile_used, (int)h->header.G.nz, sw, sl, tag,
-                           nchunks, h->d_image, h->d_ctr);
+                           (int)mc, tp.nb_log2, ng, tp.tile_used, (int)h->header.G.nz, sw, sl, list,
+                           nlist, h->d_image, h->d_ctr);
         HIPCHK(hipGetLastError());
     }
     if ((rc = end_timed(h))) return rc;
@@ -1509,7 +1523,7 @@ int nxc_image_mode(nxc_handle *h, int mode, int tile_pixels, int64_t slab_sample
         return fail(NXC_ERR_ARG, "slab_samples is 0 (default) or at most 2^31");
     h->image_mode = mode;
     h->tile_pixels = tile_pixels ? tile_pixels : NXC_TILE_PIXELS;
-    h->tile_slab = slab_samples ? slab_samples : int64_t(1) << 27;
+    h->tile_slab = slab_samples ? slab_samples : int64_t(1) << 28;
     return NXC_OK;
     });
 }

@@ -802,7 +802,7 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
             int mc, int nb_log2, const T *__restrict__ x, const T *__restrict__ y,
             const T *__restrict__ z, const T *__restrict__ vy, const T *__restrict__ frac,
             double *__restrict__ sw, unsigned short *__restrict__ sl,
-            unsigned short *__restrict__ tag, unsigned *__restrict__ nchunks,
+            unsigned short *__restrict__ list, unsigned *__restrict__ nlist,
             DevCounters *__restrict__ ctr)
 {
     constexpr int CAP = NXC_TILE_CHUNK, U = NXC_TILE_UNROLL;
@@ -815,17 +815,25 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
     unsigned *const cnt = reinterpret_cast<unsigned *>(nxc_lds + s0 + nb * CAP * 10);    // [nb]
     unsigned *const nch = cnt + nb;                   // chunks written so far
     unsigned *const again = nch + 1;                  // [2]: somebody still holds an entry
+    unsigned *const bc = again + 2;                   // [nb]: chunks written per tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
-    if (tid < nb + 3) cnt[tid] = 0;
+    if (tid < 2 * nb + 3) cnt[tid] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * span;
     const int64_t hi = lo + span < p ? lo + span : p;
     const size_t chunk0 = (size_t)blockIdx.x * (size_t)mc;
 
-    // a wave moves staging block b (n entries) to the workgroup's next chunk
+    // a wave moves staging block b (n entries) to the workgroup's next chunk and enters the chunk
+    // in tile b's list (one wave serves a tile at any time: bc[b] needs no atomic)
+    unsigned short *const my_list = list + ((size_t)blockIdx.x * nb) * (size_t)mc;
     auto flush = [&](int b, int n) {
         unsigned j = 0;
-        if (lane == 0) j = atomicAdd(nch, 1u);
+        if (lane == 0) {
+            j = atomicAdd(nch, 1u);
+            const unsigned i = bc[b];
+            bc[b] = i + 1;
+            my_list[(size_t)b * mc + i] = (unsigned short)j;
+        }
         j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
         const size_t c = (chunk0 + j) * CAP;
 #pragma unroll
@@ -833,7 +841,6 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
             const int e = lane + 64 * t;
             if (e < n) { sw[c + e] = stw[b * CAP + e]; sl[c + e] = stl[b * CAP + e]; }
         }
-        if (lane == 0) tag[chunk0 + j] = (unsigned short)((b << 8) | (n - 1));
     };
 
     unsigned long long my_samples = 0, my_binned = 0, my_nonfinite = 0;
@@ -911,12 +918,12 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
             if (!more) break;
         }
     }
+    // the partial blocks; nlist = chunks of the tile << 16 | entries of the last one
     for (int b = wid; b < nb; b += nwaves) {
         const int n = (int)cnt[b];
         if (n > 0) flush(b, n);
+        if (lane == 0) nlist[(size_t)blockIdx.x * nb + b] = bc[b] << 16 | (unsigned)(n > 0 ? n : CAP);
     }
-    lds_barrier();
-    if (tid == 0) nchunks[blockIdx.x] = *nch;
     flush_counter(&ctr->samples, my_samples);
     flush_counter(&ctr->samples_binned, my_binned);
     flush_counter(&ctr->nonfinite, my_nonfinite);
@@ -931,10 +938,10 @@ __global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
 k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n_prod, int mc,
               int nb_log2, int ng, int tile_used, int nz,
               const double *__restrict__ sw, const unsigned short *__restrict__ sl,
-              const unsigned short *__restrict__ tag, const unsigned *__restrict__ nchunks,
+              const unsigned short *__restrict__ list, const unsigned *__restrict__ nlist,
               double *__restrict__ acc2, DevCounters *__restrict__ ctr)
 {
-    constexpr int CAP = NXC_TILE_CHUNK;
+    constexpr int CAP = NXC_TILE_CHUNK, E = CAP / 64;
     int t0 = 0;
     ImageRegs IR = {};
     if (WEIGH) {
@@ -945,49 +952,62 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
     double *const tw = reinterpret_cast<double *>(nxc_lds + t0);
     unsigned *const tc = reinterpret_cast<unsigned *>(nxc_lds + t0 + 8 * NXC_TILE_PIXELS);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nwaves = blockDim.x >> 6;
-    const int b = blockIdx.x & ((1 << nb_log2) - 1), g = blockIdx.x >> nb_log2;
+    const int nb = 1 << nb_log2;
+    const int b = blockIdx.x & (nb - 1), g = blockIdx.x >> nb_log2;
     for (int i = tid; i < tile_used; i += blockDim.x) { tw[i] = 0.0; tc[i] = 0u; }
     __syncthreads();
     unsigned long long my_binned = 0, my_nonfinite = 0;
-    for (int k = g; k < n_prod; k += ng) {
-        const unsigned nck = nchunks[k];
+    // one chunk: E entries per lane
+    auto fetch = [&](size_t c, int n, double (&pay)[E], int (&loc)[E]) {
+#pragma unroll
+        for (int t = 0; t < E; t++) {
+            const int e = lane + 64 * t;
+            pay[t] = 0.0; loc[t] = 0;
+            if (e < n) { pay[t] = sw[c + e]; loc[t] = sl[c + e]; }
+        }
+    };
+    auto add = [&](int n, const double (&pay)[E], const int (&loc)[E]) {
+#pragma unroll
+        for (int t = 0; t < E; t++) {
+            if (lane + 64 * t < n) {
+                double w = pay[t];
+                bool ok = true;
+                if (WEIGH) {
+                    const double vy = (double)__int_as_float(__double2loint(pay[t]));
+                    const double fw = (double)__int_as_float(__double2hiint(pay[t]));
+                    ok = image_weight(lds_header().G, IR, vy + IR.vrplanet, fw, w);
+                    my_binned += ok;
+                    my_nonfinite += !ok;
+                }
+                if (ok) {
+                    if (w != 0.0) unsafeAtomicAdd(&tw[loc[t]], w);
+                    atomicAdd(&tc[loc[t]], 1u);
+                }
+            }
+        }
+    };
+    // a wave takes whole producers; their lists name the chunks of this tile, so nothing is
+    // searched, and two chunks are in flight per wave
+    for (int k = g + wid * ng; k < n_prod; k += nwaves * ng) {
+        const unsigned nl = nlist[(size_t)k * nb + b];
+        const int n = (int)(nl >> 16), last = (int)(nl & 0xffffu);
+        const unsigned short *const L = list + ((size_t)k * nb + b) * (size_t)mc;
         const size_t c0 = (size_t)k * (size_t)mc;
-        for (unsigned j0 = (unsigned)wid * 64u; j0 < nck; j0 += (unsigned)nwaves * 64u) {
-            const unsigned j = j0 + lane;
-            const unsigned tg = j < nck ? tag[c0 + j] : 0xffffu;
-            unsigned long long m = __ballot(j < nck && (int)(tg >> 8) == b);
-            while (m) {
-                const int l = __builtin_ctzll(m);
-                m &= m - 1;
-                const int n = (__shfl((int)tg, l, 64) & 255) + 1;
-                const size_t c = (c0 + j0 + l) * CAP;
-                double pay[CAP / 64];
-                int loc[CAP / 64];
-#pragma unroll
-                for (int t = 0; t < CAP / 64; t++) {
-                    const int e = lane + 64 * t;
-                    pay[t] = 0.0; loc[t] = 0;
-                    if (e < n) { pay[t] = sw[c + e]; loc[t] = sl[c + e]; }
-                }
-#pragma unroll
-                for (int t = 0; t < CAP / 64; t++) {
-                    const int e = lane + 64 * t;
-                    if (e < n) {
-                        double w = pay[t];
-                        bool ok = true;
-                        if (WEIGH) {
-                            const double vy = (double)__int_as_float(__double2loint(pay[t]));
-                            const double fw = (double)__int_as_float(__double2hiint(pay[t]));
-                            ok = image_weight(lds_header().G, IR, vy + IR.vrplanet, fw, w);
-                            my_binned += ok;
-                            my_nonfinite += !ok;
-                        }
-                        if (ok) {
-                            if (w != 0.0) unsafeAtomicAdd(&tw[loc[t]], w);
-                            atomicAdd(&tc[loc[t]], 1u);
-                        }
-                    }
-                }
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int id = i0 + lane < n ? (int)L[i0 + lane] : 0;
+            const int m = n - i0 < 64 ? n - i0 : 64;
+            for (int l = 0; l < m; l += 2) {
+                const bool two = l + 1 < m;
+                const int ja = __builtin_amdgcn_readlane(id, l);
+                const int jb = __builtin_amdgcn_readlane(id, two ? l + 1 : l);
+                const int na = i0 + l == n - 1 ? last : CAP;
+                const int nb_ = two ? (i0 + l + 1 == n - 1 ? last : CAP) : 0;
+                double pa[E], pb[E];
+                int la[E], lb[E];
+                fetch((c0 + ja) * CAP, na, pa, la);
+                fetch((c0 + jb) * CAP, nb_, pb, lb);
+                add(na, pa, la);
+                add(nb_, pb, lb);
             }
         }
     }

@@ -103,7 +103,9 @@ def main():
         call_ms = (time.perf_counter() - t0)*1e3
         ms_batch = ctx.last_kernel_ms()
         Pb = res['store'].total
-        res['store'].free()
+        if _ < reps - 1:
+            res['store'].free()
+    batch_store = res['store']                  # stays in HBM for the image lines below
     workb = ctx.counters()["particle_steps"]
     line(f'k_const_fused<ROWS> {nchunks} chunks in one launch', ms_batch, Pb,
          'live records written', 72,
@@ -130,13 +132,31 @@ def main():
         with quiet():
             img = ModelImage(inputs, {'quantity': q, 'dims': '512,512'}, context=ctx)
         img._set_image(ctx, float(out.aplanet), float(out.vrplanet), False)
+        per = 40 if q == 'radiance' else 32
+        ctx.image_mode('atomics')
         for _ in range(reps):
             ctx.image_clear()
             ctx.image_accumulate(xs, ys, zs, vys, fs)
             ms = ctx.last_kernel_ms()
         c = ctx.counters()
-        line(f'k_image[{q}]', ms, len(xs), 'samples', 40 if q == 'radiance' else 32,
-             f'{c["samples_binned"]} of {c["samples"]} samples inside the 512x512 image')
+        line(f'k_image[{q}]', ms, len(xs), 'samples', per,
+             f'{c["samples_binned"]} of {c["samples"]} samples inside the 512x512 image; one '
+             f'global atomic pair per binned sample')
+        # the resident rows of the 13-chunk launch above, both ways
+        for mode, name in (('atomics', f'k_image[{q}] resident rows'),
+                           ('tiles', f'k_image_bin + k_image_tiles[{q}] resident rows')):
+            ctx.image_mode(mode)
+            for _ in range(reps):
+                ctx.image_clear()
+                ctx.image_accumulate_rows(batch_store)
+                ms = ctx.last_kernel_ms()
+            c = ctx.counters()
+            line(name, ms, batch_store.total, 'samples', per,
+                 f'{c["samples_binned"]} of {c["samples"]} samples inside the 512x512 image'
+                 + ('; filed by image tile in LDS, summed per tile in LDS, one global atomic pair '
+                    'per touched pixel and tile group' if mode == 'tiles' else ''))
+        ctx.image_mode('auto')
+    batch_store.free()
 
     S = 512
     pos, look = synthetic_orbit(S)
