@@ -1079,7 +1079,7 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image_bin<T, DEFER>,
                                                         NXC_IMAGE_BLOCK, tp.lds_bin));
     const int nb = 1 << tp.nb_log2;
-    const int64_t per_trip = (int64_t)NXC_IMAGE_BLOCK * NXC_TILE_UNROLL;
+    const int64_t per_trip = (int64_t)NXC_IMAGE_BLOCK * nxc_tile_unroll<T>();
     const int ng = std::max(1, h->n_cu / nb);             // consumer groups per tile
     int64_t slab_max = std::min<int64_t>(p, h->tile_slab), slab, prod, span, mc;
     size_t o_sl, o_list, o_n;

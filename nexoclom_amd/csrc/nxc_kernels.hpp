@@ -750,10 +750,18 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 // ix = b (mod nb): every tile sees the same cut through the cloud, so the static assignment of
 // tiles to workgroups is balanced.  Packet counts are exact as before; the weight sums differ from
 // k_image's by the order of fp64 additions only (both are unordered).
-constexpr int NXC_TILE_CHUNK = 256;         // entries per chunk
+#ifndef NXC_TILE_CHUNK_N
+#define NXC_TILE_CHUNK_N 256
+#endif
+constexpr int NXC_TILE_CHUNK = NXC_TILE_CHUNK_N;     // entries per chunk
 constexpr int NXC_TILE_MAX = 32;            // tiles per image at most
 constexpr int NXC_TILE_PIXELS = 8192;       // pixels per tile at most (96 KB of LDS)
-constexpr int NXC_TILE_UNROLL = 2;          // samples per thread between two workgroup barriers
+#ifndef NXC_TILE_UNROLL_N
+#define NXC_TILE_UNROLL_N 4
+#endif
+// samples per thread between two workgroup barriers: 4 float32 samples (1.42 / 1.26 / 1.20 / 1.19 ms
+// per 1.34e8 rows for 1 / 2 / 3 / 4), 2 of 64 bits (4 would spill)
+template <typename T> constexpr int nxc_tile_unroll() { return sizeof(T) == 4 ? NXC_TILE_UNROLL_N : 2; }
 
 // Workgroup barrier that orders LDS traffic only: the global loads of the next samples stay in
 // flight across it (__syncthreads waits for vmcnt(0) as well).
@@ -805,7 +813,7 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
             unsigned short *__restrict__ list, unsigned *__restrict__ nlist,
             DevCounters *__restrict__ ctr)
 {
-    constexpr int CAP = NXC_TILE_CHUNK, U = NXC_TILE_UNROLL;
+    constexpr int CAP = NXC_TILE_CHUNK, U = nxc_tile_unroll<T>();
     stage_tables(blob, stage_bytes);
     const ImageRegs IR = image_regs(lds_header().G);
     const int nb = 1 << nb_log2;
