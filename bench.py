@@ -247,6 +247,7 @@ def stored_samples_leg(ctx, inputs, img, aplanet, vrplanet, quantity, n=1_000_00
         ach = per_sample*store.total/(k_ms*1e-3)/1e9
         leg[mode] = {'kernel': 'k_image' if mode == 'atomics' else 'k_image_bin + k_image_tiles',
                      'kernel_ms': k_ms, 'samples_per_s': store.total/(k_ms*1e-3),
+                     'pixels_per_s': img.dims[0]*img.dims[1]/(k_ms*1e-3),
                      'binned': ctx.counters()['samples_binned'],
                      'roofline': {'bound': 'atomic requests' if mode == 'atomics' else 'hbm',
                                   'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
