@@ -1077,9 +1077,9 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
     if ((rc = prep_kernel(k_image_bin<T, DEFER>, tp.lds_bin))) return rc;
     if ((rc = prep_kernel(k_image_tiles<DEFER>, lds_tiles))) return rc;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image_bin<T, DEFER>,
-                                                        NXC_IMAGE_BLOCK, tp.lds_bin));
+                                                        NXC_TILE_BIN_BLOCK, tp.lds_bin));
     const int nb = 1 << tp.nb_log2;
-    const int64_t per_trip = (int64_t)NXC_IMAGE_BLOCK * nxc_tile_unroll<T>();
+    const int64_t per_trip = (int64_t)NXC_TILE_BIN_BLOCK * nxc_tile_unroll<T>();
     const int ng = std::max(1, h->n_cu / nb);             // consumer groups per tile
     int64_t slab_max = std::min<int64_t>(p, h->tile_slab), slab, prod, span, mc;
     size_t o_sl, o_list, o_n;
@@ -1114,7 +1114,7 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
     for (int64_t first = 0; first < p; first += slab) {
         const int64_t n = std::min<int64_t>(slab, p - first);
         const int64_t grid = (n + span - 1) / span;       // <= prod; the scratch regions keep their place
-        hipLaunchKernelGGL((k_image_bin<T, DEFER>), dim3((unsigned)grid), dim3(NXC_IMAGE_BLOCK),
+        hipLaunchKernelGGL((k_image_bin<T, DEFER>), dim3((unsigned)grid), dim3(NXC_TILE_BIN_BLOCK),
                            tp.lds_bin, h->stream, h->d_blob_img, (int64_t)h->img_bytes, n, span,
                            (int)mc, tp.nb_log2, dx + first, dy + first, dz + first, dvy + first,
                            dfrac + first, sw, sl, list, nlist, h->d_ctr);

@@ -804,8 +804,12 @@ NXC_DEV void image_add_pairs_n(bool has, int pix, double w, double cnt, double *
 // half of its lanes whose sample fell inside the image; possible whenever the samples are float32
 // values (stored rows, or the down-cast image), since the masked fraction is frac or a zero.
 // Otherwise the payload is the fp64 weight itself.
+#ifndef NXC_TILE_BIN_BLOCK_N
+#define NXC_TILE_BIN_BLOCK_N 1024
+#endif
+constexpr int NXC_TILE_BIN_BLOCK = NXC_TILE_BIN_BLOCK_N;
 template <typename T, bool DEFER>
-__global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
+__global__ void __launch_bounds__(NXC_TILE_BIN_BLOCK)
 k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p, int64_t span,
             int mc, int nb_log2, const T *__restrict__ x, const T *__restrict__ y,
             const T *__restrict__ z, const T *__restrict__ vy, const T *__restrict__ frac,
@@ -949,7 +953,7 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
               const unsigned short *__restrict__ list, const unsigned *__restrict__ nlist,
               double *__restrict__ acc2, DevCounters *__restrict__ ctr)
 {
-    constexpr int CAP = NXC_TILE_CHUNK, E = CAP / 64;
+    constexpr int CAP = NXC_TILE_CHUNK, E = CAP / 64, NF = 512 / CAP;
     int t0 = 0;
     ImageRegs IR = {};
     if (WEIGH) {
@@ -1004,18 +1008,18 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int id = i0 + lane < n ? (int)L[i0 + lane] : 0;
             const int m = n - i0 < 64 ? n - i0 : 64;
-            for (int l = 0; l < m; l += 2) {
-                const bool two = l + 1 < m;
-                const int ja = __builtin_amdgcn_readlane(id, l);
-                const int jb = __builtin_amdgcn_readlane(id, two ? l + 1 : l);
-                const int na = i0 + l == n - 1 ? last : CAP;
-                const int nb_ = two ? (i0 + l + 1 == n - 1 ? last : CAP) : 0;
-                double pa[E], pb[E];
-                int la[E], lb[E];
-                fetch((c0 + ja) * CAP, na, pa, la);
-                fetch((c0 + jb) * CAP, nb_, pb, lb);
-                add(na, pa, la);
-                add(nb_, pb, lb);
+            for (int l = 0; l < m; l += NF) {              // NF chunks (512 entries) in flight
+                double pay[NF][E];
+                int loc[NF][E], cn[NF];
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    const bool there = l + f < m;
+                    const int j = __builtin_amdgcn_readlane(id, there ? l + f : l);
+                    cn[f] = there ? (i0 + l + f == n - 1 ? last : CAP) : 0;
+                    fetch((c0 + j) * CAP, cn[f], pay[f], loc[f]);
+                }
+#pragma unroll
+                for (int f = 0; f < NF; f++) add(cn[f], pay[f], loc[f]);
             }
         }
     }
