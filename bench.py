@@ -254,6 +254,12 @@ def stored_samples_leg(ctx, inputs, img, aplanet, vrplanet, quantity, n=1_000_00
                                   'frac': ach/HBM_PEAK_GBS}}
     ctx.image_mode('auto')
     store.free()
+    try:        # HBM bytes really moved by the two tile passes (PMC, profiles/traffic.json)
+        per = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        leg['tiles']['roofline']['traffic'] = per['image_tiles_bytes_per_sample']*leg['samples']
+        leg['tiles']['roofline']['traffic_source'] = per['image_tiles_source']
+    except (OSError, ValueError, KeyError):
+        leg['tiles']['roofline']['traffic'] = None
     return leg
 
 

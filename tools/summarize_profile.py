@@ -73,7 +73,34 @@ if dom:
                     json.loads(open(bl).read().strip().splitlines()[-1])['particle_steps_per_pass']
             except (ValueError, KeyError, IndexError):
                 pass
-        json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
+        tfile = os.path.join(dst, 'traffic.json')
+        try:                                    # entries of other kernels stay
+            keep = {k: v for k, v in json.load(open(tfile)).items() if k.startswith('image_tiles')}
+        except (OSError, ValueError):
+            keep = {}
+        json.dump(dict(keep, **traffic), open(tfile, 'w'), indent=1)
+
+# the tiled image of stored samples (tools/profile_kernels.sh): bytes really moved per sample
+tiles = [k for k in summary if 'k_image_bin<float, true>' in k or 'k_image_tiles<true>' in k]
+units = None
+if os.path.exists(bl):
+    for ln in open(bl):
+        if 'k_image_bin + k_image_tiles[radiance]' in ln:
+            units = json.loads(ln)['units']
+if len(tiles) == 2 and units and all('FETCH_SIZE' in summary[k] and 'WRITE_SIZE' in summary[k]
+                                     for k in tiles):
+    total = sum(summary[k]['FETCH_SIZE']['mean_per_launch']*2048 +
+                summary[k]['WRITE_SIZE']['mean_per_launch']*1024 for k in tiles)
+    tfile = os.path.join(dst, 'traffic.json')
+    try:
+        cur = json.load(open(tfile))
+    except (OSError, ValueError):
+        cur = {}
+    cur['image_tiles_bytes_per_sample'] = total/units
+    cur['image_tiles_source'] = (f'profiles/{tag}_pmc.json: (FETCH_SIZE x 2 + WRITE_SIZE) x 1024 of '
+                                 f'k_image_bin<float, true> + k_image_tiles<true>, {units} float32 '
+                                 f'rows per launch pair (radiance and column launches averaged)')
+    json.dump(cur, open(tfile, 'w'), indent=1)
 print(json.dumps({'kernels': list(summary), 'traffic': traffic}, indent=1))
 for k, d in summary.items():
     print(k)
