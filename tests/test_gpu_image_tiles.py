@@ -162,3 +162,40 @@ def test_resident_rows_through_the_tiles(tiles, narrow):
     assert out['tiles'][2] == out['atomics'][2] and out['tiles'][2]['samples'] == b - a
     assert out['tiles'][1].sum() > 1e5 and np.array_equal(out['tiles'][1], out['atomics'][1])
     np.testing.assert_allclose(out['tiles'][0], out['atomics'][0], rtol=1e-12, atol=0)
+
+
+def test_produce_image_at_full_size_both_ways_and_against_the_fused_pass(tiles):
+    """The two-stage flow at the size of BASELINE configs[1]: Input.run(1e6) leaves 1.3e8 float32
+    rows in HBM; produce_image over them through the tiles (the default at this size) and through
+    k_image gives the same packet count in every pixel -- and the count image of the FUSED pass
+    over the same seeded packets (ModelImage(npackets=...), the path pinned against the C oracle
+    at this size in test_gpu_edge_fullsize.py)."""
+    import contextlib
+    import io
+    import nexoclom_amd
+    from nexoclom_amd import Input, ModelImage
+    ctx = tiles
+    inputs = Input(os.path.join(os.path.dirname(nexoclom_amd.__file__), 'inputfiles',
+                                'Na.mercury.bench.input'))
+    params = {'quantity': 'radiance', 'dims': '512,512'}
+    with contextlib.redirect_stdout(io.StringIO()):
+        inputs.run(1e6, seed=5, context=ctx, sampler='device', generator='pcg64')
+        outs = inputs._catalogue
+        images = {}
+        for mode in ('auto', 'atomics', 'tiles'):
+            ctx.image_mode(mode)
+            images[mode] = inputs.produce_image(params, context=ctx)
+        ctx.image_mode('auto')
+        fused = ModelImage(inputs, params, npackets=len(outs)*len(outs[0]),
+                           packs_per_it=len(outs[0]), seed=5, sampler='device', generator='pcg64',
+                           context=ctx)
+    rows = sum(o._nrows for o in outs)
+    assert rows > 1.2e8
+    a, t = images['atomics'], images['tiles']
+    assert t.packet_image.sum() > 6e7
+    assert np.array_equal(t.packet_image, a.packet_image)
+    assert np.array_equal(t.packet_image, images['auto'].packet_image)
+    assert np.array_equal(t.packet_image, fused.packet_image)
+    np.testing.assert_allclose(t.image, a.image, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(t.image, fused.image, rtol=1e-11, atol=0)
+    assert t.totalsource == a.totalsource == fused.totalsource
