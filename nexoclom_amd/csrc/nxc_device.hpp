@@ -315,6 +315,21 @@ struct StepW {
     double w[21];
 };
 
+// One term of a tableau sum, acc + w k.  NumPy rounds the product and the sum (rk5.py:33-35: two
+// roundings per term); here -- and, call for call, in the C oracle (oracle/c/oracle.c: rk5_body) --
+// the term is ONE fused multiply-add, i.e. the exact product enters the sum and the result is
+// rounded once: at most half an ulp of the sum closer to the true value per term, 98 fewer fp64
+// instructions per step (14 terms x 7 components).  -DNXC_TABLEAU_TWO_ROUNDINGS (with the oracle's
+// -DORACLE_TABLEAU_TWO_ROUNDINGS) restores NumPy's roundings.
+NXC_DEV double nxc_tab_fma(double w, double k, double acc)
+{
+#ifdef NXC_TABLEAU_TWO_ROUNDINGS
+    return acc + w * k;
+#else
+    return __builtin_fma(w, k, acc);
+#endif
+}
+
 // s[8] = t_remaining, x, y, z, vx, vy, vz, frac (in/out).  d[8] (DELTA only) = the reference's
 // error estimate |h * sum_{i<6} (B5-B4)_i k_i| (rk5.py:38-46; the 7th stage is left out there).
 // Each stage is accumulated from zero in the order i = 0..n with terms (h*a)*k and the initial
@@ -348,13 +363,13 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
         for (int i = 1; i <= n; i++) {
             if (Tableau::A[n + 1][i] == 0.0) continue;   // b5[1] = 0: the term is a zero
             const double w = UNIFORM_H ? W.w[n * (n + 1) / 2 + i] : h * Tableau::A[n + 1][i];
-            nx += w * kv[i][0];
-            ny += w * kv[i][1];
-            nz += w * kv[i][2];
-            nvx += w * ka[i][0];
-            nvy += w * ka[i][1];
-            nvz += w * ka[i][2];
-            nlf -= w * kl[i];
+            nx = nxc_tab_fma(w, kv[i][0], nx);
+            ny = nxc_tab_fma(w, kv[i][1], ny);
+            nz = nxc_tab_fma(w, kv[i][2], nz);
+            nvx = nxc_tab_fma(w, ka[i][0], nvx);
+            nvy = nxc_tab_fma(w, ka[i][1], nvy);
+            nvz = nxc_tab_fma(w, ka[i][2], nvz);
+            nlf = nxc_tab_fma(-w, kl[i], nlf);
         }
         px = nx + x0; py = ny + y0; pz = nz + z0;
         vx = nvx + vx0; vy = nvy + vy0; vz = nvz + vz0;
@@ -365,13 +380,13 @@ NXC_DEV void rk5_step(const ForceK &F, const LutView &T, double (&s)[8], double 
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const double bd = Tableau::B5[i] - Tableau::B4[i];
-            e[0] += bd * kv[i][0];
-            e[1] += bd * kv[i][1];
-            e[2] += bd * kv[i][2];
-            e[3] += bd * ka[i][0];
-            e[4] += bd * ka[i][1];
-            e[5] += bd * ka[i][2];
-            e[6] += bd * kl[i];
+            e[0] = nxc_tab_fma(bd, kv[i][0], e[0]);
+            e[1] = nxc_tab_fma(bd, kv[i][1], e[1]);
+            e[2] = nxc_tab_fma(bd, kv[i][2], e[2]);
+            e[3] = nxc_tab_fma(bd, ka[i][0], e[3]);
+            e[4] = nxc_tab_fma(bd, ka[i][1], e[4]);
+            e[5] = nxc_tab_fma(bd, ka[i][2], e[5]);
+            e[6] = nxc_tab_fma(bd, kl[i], e[6]);
         }
         d[0] = 0.0;
 #pragma unroll

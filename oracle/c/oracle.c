@@ -174,6 +174,21 @@ void ora_state(const ora_forces *f, int64_t n, const double *x, const double *y,
         state1(f, x[i], y[i], z[i], vy[i], &ax[i], &ay[i], &az[i], &ion[i]);
 }
 
+/* One term of a tableau sum, acc + w k (rk5.py:33-35,41-43).  NumPy rounds the product and the
+ * sum; the kernels under test fuse the two (one rounding, nxc_device.hpp: nxc_tab_fma), and so does
+ * this checker, call for call, so that the two stay bit-identical.  Against the reference's own
+ * vectors that is at most half an ulp of the sum per term (tests/test_oracle_golden.py pins a step at
+ * rtol 1e-13, the NumPy oracle keeps NumPy's roundings).  -DORACLE_TABLEAU_TWO_ROUNDINGS restores
+ * them here (with -DNXC_TABLEAU_TWO_ROUNDINGS in the kernels). */
+static inline double tab_fma(double w, double k, double acc)
+{
+#ifdef ORACLE_TABLEAU_TWO_ROUNDINGS
+    return acc + w * k;
+#else
+    return fma(w, k, acc);
+#endif
+}
+
 /* One step for one packet.  s[8] in/out; d[8] (nullable) receives |h * sum_{i<6} (b5-b4)_i k_i|. */
 static void rk5_body(const ora_forces *f, const ora_bodies *b, int64_t k, double *s, double h,
                      double *d)
@@ -191,10 +206,10 @@ static void rk5_body(const ora_forces *f, const ora_bodies *b, int64_t k, double
         for (int i = 0; i <= n; i++) {
             double w = h * AT[n+1][i];
             for (int c = 0; c < 3; c++) {
-                nx[1+c] += w * kv[i][c];
-                nx[4+c] += w * ka[i][c];
+                nx[1+c] = tab_fma(w, kv[i][c], nx[1+c]);
+                nx[4+c] = tab_fma(w, ka[i][c], nx[4+c]);
             }
-            nx[7] -= w * kl[i];
+            nx[7] = tab_fma(-w, kl[i], nx[7]);
         }
         for (int c = 0; c < 8; c++) st[c] = nx[c] + y0[c];
     }
@@ -203,10 +218,10 @@ static void rk5_body(const ora_forces *f, const ora_bodies *b, int64_t k, double
         for (int i = 0; i < 6; i++) {
             double bd = B5[i] - B4[i];
             for (int c = 0; c < 3; c++) {
-                acc[1+c] += bd * kv[i][c];
-                acc[4+c] += bd * ka[i][c];
+                acc[1+c] = tab_fma(bd, kv[i][c], acc[1+c]);
+                acc[4+c] = tab_fma(bd, ka[i][c], acc[4+c]);
             }
-            acc[7] += bd * kl[i];
+            acc[7] = tab_fma(bd, kl[i], acc[7]);
         }
         for (int c = 0; c < 8; c++) d[c] = fabs(h * acc[c]);
     }
