@@ -152,8 +152,8 @@ def profile_ceilings(k_ms, particle_steps, clock_mhz):
     the kernel's cycles in which a VALU instruction was issuing (``valu_busy_frac_pmc``:
     SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles, which charges a 32-bit instruction a full slot).
     ``valu_issue_floor_ms`` is the cost model of DESIGN.md section 3 instead -- per wave trip
-    608 fp64 instructions at one 4-cycle issue slot, 13 v_rcp/v_rsq_f64 at 3.3 slots, 291 32-bit
-    instructions at half a slot (profiles/cost_model.json) -- at the clock THIS run held
+    512 fp64 instructions at one 4-cycle issue slot, 13 v_rcp/v_rsq_f64 at 3.3 slots, 284 32-bit
+    instructions at half a slot (profiles/cost_model.json holds the figures used) -- at the clock THIS run held
     (``clock_mhz``: in-kernel stamps of a diagnostic launch, or the profile's if not measured)."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     cfile = os.path.join(ROOT, 'profiles', 'cost_model.json')
