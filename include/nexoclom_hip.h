@@ -355,7 +355,7 @@ int nxc_image_accumulate_f32(nxc_handle *h, int64_t p, const float *x, const flo
  * (k_image_bin + k_image_tiles: the samples are filed by image tile first, a workgroup sums a tile
  * in LDS and hands it over once -- the replacement of np.histogram2d's bincount,
  * math/histogram.py:34, at HBM speed instead of atomic-request speed); mode 0 (default) = tiles for
- * 2^23 samples and more when the image fits them (up to 32 tiles of 8192 pixels: 512 x 512),
+ * 2^17 samples and more when the image fits them (up to 32 tiles of 8192 pixels: 512 x 512),
  * atomics otherwise.  Packet counts are identical either way, weight sums equal to the order of
  * fp64 additions.  tile_pixels: 0 = 8192; slab_samples: 0 = 2^28, the samples that go through the
  * two passes at a time (their chunk scratch is 10 bytes per sample at worst); smaller values of

@@ -533,7 +533,7 @@ class Context:
     def image_mode(self, mode='auto', tile_pixels=0, slab_samples=0):
         """How stored samples reach the image: 'atomics' (one global atomic pair per binned
         sample), 'tiles' (filed by image tile, summed in LDS, handed over once per pixel), or
-        'auto' (tiles from 2^23 samples on).  Packet counts are identical either way."""
+        'auto' (tiles from 2^17 samples on).  Packet counts are identical either way."""
         self._check(self.lib.nxc_image_mode(self._h, C.c_int(self.IMAGE_MODES.get(mode, mode)),
                                             C.c_int(int(tile_pixels)),
                                             C.c_int64(int(slab_samples))))
