@@ -3,6 +3,7 @@ arguments the HIP kernels rely on."""
 from fractions import Fraction
 
 import numpy as np
+import pytest
 
 from oracle.c_oracle import COracle
 
@@ -67,3 +68,38 @@ def test_threads_do_not_change_states(coracle):
     b = coracle.integrate_const(f, X0, 30., n_iter, 25., threads=4)
     assert a['work'] == b['work'] and np.array_equal(a['final'], b['final'])
     assert np.array_equal(a['steps'], b['steps'])
+
+
+@pytest.mark.parametrize('quantity', ['radiance', 'column'])
+def test_c_oracle_against_the_reference_arithmetic_at_3000_packets(coracle, quantity):
+    """The C checker rounds like the kernels (deterministic cube / exp / log, tableau terms fused),
+    the NumPy oracle like the reference (pinned bit for bit to the reference's own rk5.py /
+    state.py).  Twelve times the golden fixture -- 3000 seeded packets, all 1667 steps, a 256 x 256
+    image of the float32 samples -- the two still agree in what north_star asks to be exact:
+    every packet's step count and the packet count of every pixel; states and brightness agree
+    far inside its 1e-6."""
+    from oracle import np_oracle as O
+    from tests import helpers as H
+    f = H.mercury_forces('Na', 1.3)
+    n, endtime, step, edge = 3000, 50000., 30., 25.
+    X0 = H.sample_x0(n, 4321, endtime)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    results, _, work = O.constant_step_driver(f, X0, endtime, step, edge)
+    im = H.image_setup(f, quantity, dims=(256, 256))
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], quantity, im['g_tables'],
+                              im['xedges'], im['zedges'], downcast=True)
+    c = coracle.integrate_const(f, X0, step, n_iter, edge, img=desc, threads=coracle.max_threads())
+    assert c['work'] == work
+    # a packet is stepped at iteration ct while its record ct - 1 is alive (Output.py:385)
+    last = (results[:, 7, :n_iter] > 0).sum(axis=1)
+    assert np.array_equal(c['steps'], last)
+    fin = results[np.arange(n), :, last]
+    np.testing.assert_allclose(c['final'], fin, rtol=1e-9, atol=1e-13)
+    s = O.samples_from_results(results, compress=True, downcast=True)
+    ref_img, ref_cnt, _, _ = O.create_image(s['x'], s['y'], s['z'], s['vy'], s['frac'], f.vrplanet,
+                                            im['M'], quantity, im['g_tables'], im['dims'],
+                                            im['xrange'], im['zrange'], im['apix'], matmul=False)
+    assert ref_cnt.sum() > 1e5
+    assert np.array_equal(c['counts'], ref_cnt.astype(np.uint64))        # bit-exact packet counts
+    np.testing.assert_allclose(c['image'], ref_img, rtol=1e-6, atol=0)   # north_star
+    np.testing.assert_allclose(c['image'], ref_img, rtol=1e-9, atol=0)   # what we get
