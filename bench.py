@@ -270,11 +270,75 @@ def fail_line(args, world, reason):
             'data': 'synthetic', 'error': reason}
 
 
-def run_rank(args, cp, make_context, emit=print):
+def run_rank(args, cp, make_context, emit=print, hard_exit_after=None):
     """Everything one rank of the bench does.  ``cp``: the control plane (rank, world,
-    allgather_bytes, init_rccl, close); ``make_context()``: this rank's device context (raises
-    hip_api.HipError when there is none).  Rank 0 hands the JSON line to ``emit``.  Returns the
-    process exit code."""
+    allgather_bytes, init_rccl, watch, announce_failure, close); ``make_context()``: this rank's
+    device context (raises hip_api.HipError when there is none).  Rank 0 hands the JSON line to
+    ``emit``.  Returns the process exit code.
+
+    No rank can hang the job: every wait on a collective carries a deadline (nxc_comm_set_timeout,
+    NXC_COLLECTIVE_TIMEOUT_S, default 120 s) after which the communicator is aborted and the
+    call raises; a rank that raises -- anything, anywhere after the control plane is up -- tells
+    the others through the control plane's failure channel, whose watcher ends their wait at
+    once (``comm_request_abort``); a rank that dies without a word is noticed by its closed
+    socket.  Rank 0 then prints the ``"value": null`` line with the reason and every rank returns
+    1.  ``hard_exit_after`` (seconds; main() sets it): a rank whose main thread still has not
+    come back that long after a peer's failure was announced (it sits in a call that cannot be
+    interrupted, e.g. ncclCommInitRank) prints the line and leaves with os._exit(1)."""
+    import traceback
+    state = {'ctx': None, 'emitted': False, 'done': False}
+
+    def emit_once(text):
+        if not state['emitted']:
+            state['emitted'] = True
+            emit(text)
+
+    def leave_now(reason):
+        if state['done']:
+            return
+        if cp.rank == 0:
+            emit_once(json.dumps(fail_line(args, cp.world, reason)))
+        sys.stderr.write(f'[bench rank {cp.rank}] leaving: {reason}\n')
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
+
+    def on_peer_failure(reason):
+        ctx = state['ctx']
+        if ctx is not None and hasattr(ctx, 'comm_request_abort'):
+            ctx.comm_request_abort()
+        if hard_exit_after is not None:
+            import threading
+            timer = threading.Timer(hard_exit_after, leave_now, args=(reason,))
+            timer.daemon = True
+            timer.start()
+
+    try:
+        rc = _run_rank(args, cp, make_context, emit_once, state, on_peer_failure)
+        state['done'] = True
+        return rc
+    except Exception as exc:                        # noqa: BLE001 -- whatever it is, nobody hangs
+        why = f'{type(exc).__name__}: {exc}'
+        peer = getattr(cp, 'failure', None)
+        if peer and peer not in why:
+            why = f'{peer} (seen on rank {cp.rank} as {why})'
+        sys.stderr.write(f'[bench rank {cp.rank}] {why}\n{traceback.format_exc()}')
+        if hasattr(cp, 'announce_failure'):
+            cp.announce_failure(why)
+        ctx = state['ctx']
+        if ctx is not None and hasattr(ctx, 'comm_abort'):
+            try:
+                ctx.comm_abort()
+            except Exception:                       # noqa: BLE001
+                pass
+        if cp.rank == 0:
+            emit_once(json.dumps(fail_line(args, cp.world, why)))
+        state['done'] = True
+        cp.close()
+        return 1
+
+
+def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
     from nexoclom_amd import Input, Output, ModelImage, hip_api
     from nexoclom_amd.distributed import chunk_plan
     from nexoclom_amd.Output import n_output_steps
@@ -296,6 +360,9 @@ def run_rank(args, cp, make_context, emit=print):
         ctx = make_context()
     except hip_api.HipError as exc:
         err = str(exc)
+    state['ctx'] = ctx
+    if hasattr(cp, 'watch'):
+        cp.watch(on_peer_failure)
     problems = [p.decode() for p in cp.allgather_bytes(err.encode())]
     if any(problems):
         if rank == 0:
@@ -526,10 +593,26 @@ def main():
     from nexoclom_amd import hip_api
     from nexoclom_amd.distributed import ControlPlane, pick_device
     world = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
-    cp = ControlPlane(world)
+    rank = int(os.environ.get('RANK', '0')) if world > 1 else 0
+    try:
+        cp = ControlPlane(world, timeout=float(os.environ.get('NXC_CONTROL_TIMEOUT_S', '180')))
+    except (TimeoutError, OSError, ValueError) as exc:
+        # some rank never started: there is no job to measure
+        if rank == 0:
+            print(json.dumps(fail_line(args, world, f'control plane: {exc}')), flush=True)
+        sys.stderr.write(f'[bench rank {rank}] control plane: {exc}\n')
+        sys.exit(1)
     if hip_api.device_count() < 1:
+        cp.announce_failure('no HIP device')
         raise SystemExit('bench.py needs a HIP device; there is no CPU fallback')
-    sys.exit(run_rank(args, cp, lambda: hip_api.Context(pick_device(cp))))
+    rc = run_rank(args, cp, lambda: hip_api.Context(pick_device(cp)), hard_exit_after=45.0)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if rc:
+        # a failed job leaves without tearing the device state down: a stream may still hold the
+        # kernel of an aborted collective (a fresh exit -- nothing is re-executed)
+        os._exit(rc)
+    sys.exit(0)
 
 
 if __name__ == '__main__':

@@ -58,7 +58,9 @@ typedef enum {
     NXC_ERR_ARG = -2,        /* invalid argument / missing prerequisite call            */
     NXC_ERR_NO_DEVICE = -3,  /* no gfx950-class device visible                          */
     NXC_ERR_RCCL = -4,       /* librccl missing or a collective failed                  */
-    NXC_ERR_STATE = -5       /* handle not in the state the call needs                  */
+    NXC_ERR_STATE = -5,      /* handle not in the state the call needs                  */
+    NXC_ERR_NOMEM = -6       /* device memory: an allocation failed or the result would
+                                not fit (callers may split the work and call again)     */
 } nxc_status;
 
 /* Scalars and table consumed by state() (what Output.__init__ hangs on `output`,
@@ -427,6 +429,26 @@ int nxc_image_allreduce(nxc_handle *h);
 int nxc_allreduce_max_f64(nxc_handle *h, double *value);   /* control plane: max-over-ranks timer */
 int nxc_allreduce_sum_f64(nxc_handle *h, double *value);   /* control plane: whole-job work counters */
 int nxc_barrier(nxc_handle *h);
+/* In-place sum over the ranks of n host doubles (the per-file radiance sum of
+ * data_simulation/LOSResult.py:264-266 across GPUs: S radiances + S packet counts). */
+int nxc_allreduce_f64(nxc_handle *h, double *values, int64_t n);
+/* No wait on a collective is unbounded.  nxc_image_allreduce only enqueues; the next call that
+ * waits for the handle's stream (nxc_synchronize, a download, the scalar reductions above) polls
+ * the stream together with ncclCommGetAsyncError, and when `seconds` have passed (default 120, or
+ * the environment's NXC_COLLECTIVE_TIMEOUT_S at nxc_comm_init) -- a peer rank died or never issued
+ * its half of the collective -- it calls ncclCommAbort, leaves the handle without a communicator
+ * and returns NXC_ERR_RCCL.  The data the collective was to produce are then undefined; the process
+ * is expected to report and exit.  nxc_comm_abort does the same on request (a rank that must
+ * leave while its peers may already be inside a collective). */
+int nxc_comm_set_timeout(nxc_handle *h, double seconds);
+int nxc_comm_abort(nxc_handle *h);
+/* The one call that may come from ANOTHER thread while the owning thread waits inside the library
+ * (the control plane's failure watcher): the wait in progress, or the next collective, ends with
+ * NXC_ERR_RCCL at once instead of at the deadline. */
+int nxc_comm_request_abort(nxc_handle *h);
+/* Fault injection for the tests of the deadline: holds the handle's stream for `seconds` (<= 30;
+ * the kernel ends by itself) and marks it as a collective in flight. */
+int nxc_comm_test_stall(nxc_handle *h, double seconds);
 
 /* ---- measurement helpers for bench.py's roofline object -------------------------------------------
  * nxc_stream_copy_gbs: best of `reps` device-to-device streaming copies of `bytes` (16 B per lane),

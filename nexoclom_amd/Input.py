@@ -245,7 +245,7 @@ class Input:
                     out._adopt_x0(soa[:, g*size:(g + 1)*size])
             Output.integrate_batch(outs, context)
         except hip_api.HipError as exc:
-            if 'do not fit' not in str(exc) or len(outs) < 2:
+            if exc.code != hip_api.NXC_ERR_NOMEM or len(outs) < 2:
                 raise
             half = len(outs)//2
             print(f'{len(outs)} Outputs in one launch need more HBM than is free: two launches')

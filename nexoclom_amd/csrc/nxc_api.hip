@@ -9,11 +9,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <mutex>
 #include <new>
@@ -49,11 +51,27 @@ int guarded(F &&body) noexcept
     }
 }
 
+// A wait that ended because a collective missed its deadline (stream_sync below) leaves its
+// verdict here; the HIP-error path then reports NXC_ERR_RCCL with that text instead of the
+// stand-in hipError_t.
+thread_local std::string g_coll_failure;
+
+int fail_hip(const char *expr, hipError_t e)
+{
+    if (!g_coll_failure.empty()) {
+        std::string msg;
+        msg.swap(g_coll_failure);
+        return fail(NXC_ERR_RCCL, msg);
+    }
+    // out of device memory has a status of its own: callers split the work on it (Input.run)
+    return fail(e == hipErrorOutOfMemory ? NXC_ERR_NOMEM : NXC_ERR_HIP,
+                std::string(expr) + ": " + hipGetErrorString(e));
+}
+
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(NXC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+        if (e_ != hipSuccess) return fail_hip(#expr, e_);                                    \
     } while (0)
 
 constexpr int BLOCK_PERSIST = NXC_BLOCK_PERSIST;
@@ -67,6 +85,8 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
                               ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -88,6 +108,8 @@ int rccl_load()
     SYM(CommInitRank, "ncclCommInitRank")
     SYM(AllReduce, "ncclAllReduce")
     SYM(CommDestroy, "ncclCommDestroy")
+    SYM(CommAbort, "ncclCommAbort")
+    SYM(CommGetAsyncError, "ncclCommGetAsyncError")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     g_rccl.ok = true;
@@ -365,13 +387,84 @@ struct nxc_handle {
 
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    bool coll_pending = false;       // a collective sits on `stream` and nobody has waited for it yet
+    std::atomic<bool> abort_requested{false};   // nxc_comm_request_abort (any thread)
+    double coll_timeout_s = 120.0;   // nxc_comm_set_timeout / NXC_COLLECTIVE_TIMEOUT_S
     double *d_reduce = nullptr;      // one double for control-plane reductions
+    double *d_reduce_n = nullptr;    // nxc_allreduce_f64's staging (grow-only)
+    size_t reduce_n_cap = 0;
 };
 
 static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifetimes,
                            int64_t max_steps);
 
 namespace {
+
+// Wait for the handle's stream.  Without a collective in flight this is hipStreamSynchronize.
+// With one (nxc_image_allreduce / nxc_allreduce_* since the last wait) the wait is bounded: the
+// stream is polled together with ncclCommGetAsyncError, and when `coll_timeout_s` have passed --
+// a peer rank died or never issued its half -- the communicator is aborted (ncclCommAbort makes
+// the RCCL kernel leave), the handle is left without a communicator and the caller gets
+// NXC_ERR_RCCL (through fail_hip) instead of waiting forever.
+hipError_t stream_sync(nxc_handle *h)
+{
+    if (!h->coll_pending || !h->comm || !g_rccl.ok) {
+        h->coll_pending = false;
+        return hipStreamSynchronize(h->stream);
+    }
+    timespec t0{};
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    auto elapsed = [&]() {
+        timespec t{};
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return double(t.tv_sec - t0.tv_sec) + 1e-9 * double(t.tv_nsec - t0.tv_nsec);
+    };
+    std::string why;
+    for (long spin = 0;; spin++) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) {
+            h->coll_pending = false;
+            return hipSuccess;
+        }
+        if (q != hipErrorNotReady) {
+            h->coll_pending = false;
+            return q;
+        }
+        if (h->abort_requested.load(std::memory_order_relaxed)) {
+            why = "a peer rank reported a failure while this rank waited for a collective";
+            break;
+        }
+        if ((spin & 63) == 63) {
+            ncclResult_t async = ncclSuccess;
+            const ncclResult_t r = g_rccl.CommGetAsyncError(h->comm, &async);
+            if (r != ncclSuccess || (async != ncclSuccess && async != ncclInProgress)) {
+                why = std::string("RCCL reported an asynchronous error (") +
+                      g_rccl.GetErrorString(r != ncclSuccess ? r : async) + ")";
+                break;
+            }
+            const double dt = elapsed();
+            if (dt > h->coll_timeout_s) {
+                char buf[160];
+                std::snprintf(buf, sizeof buf,
+                              "a collective of rank %d of %d did not complete within %.1f s (a peer "
+                              "rank is gone or never joined it)", h->rank, h->nranks, h->coll_timeout_s);
+                why = buf;
+                break;
+            }
+            if (dt > 2e-3) {                       // past the latency of a healthy collective
+                timespec nap{0, 200000};
+                nanosleep(&nap, nullptr);
+            }
+        }
+    }
+    (void)g_rccl.CommAbort(h->comm);               // frees the communicator; its kernel exits
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    h->coll_pending = false;
+    g_coll_failure = why + "; the communicator was aborted";
+    return hipErrorNotReady;
+}
 
 void flush_all_pools();
 
@@ -502,7 +595,7 @@ int upload_blob(nxc_handle *h)
                                   hipMemcpyHostToDevice, h->stream));
     if (ib) HIPCHK(hipMemcpyAsync(h->d_blob + hb + fb, h->image_part.data(), ib,
                                   hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     if (h->have_image) {
         // the same image tables right behind the header: k_image stages 45 KB instead of 100+, so
         // that several of its workgroups fit a CU (it was one 256-thread group per CU)
@@ -517,7 +610,7 @@ int upload_blob(nxc_handle *h)
         HIPCHK(hipMemcpyAsync(h->d_blob_img, &hdr, sizeof(LdsHeader), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->d_blob_img + hb, h->image_part.data(), ib, hipMemcpyHostToDevice,
                               h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));      // hdr is a local
+        HIPCHK(stream_sync(h));      // hdr is a local
     }
     return NXC_OK;
 }
@@ -632,7 +725,7 @@ int upload_moon_table(nxc_handle *h, double step, int64_t n_iter)
     // pageable source: the copy is staged before the call returns
     HIPCHK(hipMemcpyAsync(h->d_moonpos, base.data(), count * sizeof(double), hipMemcpyHostToDevice,
                           h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
 }
 
@@ -757,7 +850,7 @@ int count_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge, boo
     HIPCHK(hipMemcpyAsync(steps.data(), h->d_steps, (size_t)n * sizeof(long long),
                           hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(frac.data(), h->d_scratch + 7 * n, col, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     long long acc = 0;
     for (int64_t i = 0; i < n; i++) {
         off[(size_t)i] = acc;
@@ -771,7 +864,7 @@ int count_rows(nxc_handle *h, double step, int64_t n_iter, double outeredge, boo
         return rc;
     HIPCHK(hipMemcpyAsync(h->d_offsets, off.data(), ((size_t)n + 1) * sizeof(long long),
                           hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     // the lifetimes are now known exactly: re-sort the queue by them (longest first) for pass 2
     // and for every later pass over these packets
     if ((rc = order_on_device(h, 0.0, h->d_steps, n_iter))) return rc;
@@ -791,13 +884,17 @@ int write_records(nxc_handle *h, bool narrow, size_t reserve)
     if (h->rows_total < 0 || h->rows_n != h->n_packets)
         return fail(NXC_ERR_STATE, "the trajectory rows need a preceding nxc_integrate_const_rows");
     const long long total = h->rows_total;
-    if (total == 0) return NXC_OK;
+    if (total == 0) {
+        // nothing to write: the counters of "pass 2" are zeros, not a second copy of pass 1's
+        HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
+        return NXC_OK;
+    }
     const size_t bytes = (size_t)total * 10 * (narrow ? sizeof(float) : sizeof(double));
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t grow = bytes > h->rec_cap ? bytes : 0, back = grow ? h->rec_cap : 0;
     if (grow + reserve > free_b + back + pool_bytes(h))
-        return fail(NXC_ERR_ARG, "trajectory rows do not fit in device memory; run fewer packets "
+        return fail(NXC_ERR_NOMEM, "trajectory rows do not fit in device memory; run fewer packets "
                                  "per call (the reference chunks too, Input.py:219-222)");
     if (grow > free_b + back) pool_flush(h);      // the scratch grows into what the pool holds
     // the launch groups of an Input.run differ by a per cent or so: an eighth of slack saves the
@@ -858,13 +955,13 @@ int rows_build(nxc_handle *h, bool narrow, nxc_rows **out)
         if (e == hipSuccess)
             rc = narrow ? transpose_rows<float, int>(h, h->d_rec, total, r->d_cols, r->d_index)
                         : transpose_rows<double, long long>(h, h->d_rec, total, r->d_cols, r->d_index);
-        if (e == hipSuccess && !rc) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess && !rc) e = stream_sync(h);
     }
     if (e != hipSuccess || rc) {
         if (r->d_cols) (void)hipFree(r->d_cols);
         if (r->d_index) (void)hipFree(r->d_index);
         delete r;
-        return rc ? rc : fail(NXC_ERR_HIP, std::string("rows run: ") + hipGetErrorString(e));
+        return rc ? rc : fail_hip("rows run", e);
     }
     *out = r;
     return NXC_OK;
@@ -893,10 +990,10 @@ int rows_fetch(nxc_handle *h, void *rows_out, bool narrow)
     if (r->total > 0) {
         e = hipMemcpyAsync(rows_out, r->d_cols, (size_t)r->total * 9 * (narrow ? 4 : 8),
                            hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = stream_sync(h);
     }
     nxc_rows_free(h, r);
-    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("rows copy: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail_hip("rows copy", e);
     return NXC_OK;
 }
 
@@ -1126,7 +1223,7 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
         HIPCHK(hipGetLastError());
     }
     if ((rc = end_timed(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
 }
 
@@ -1164,7 +1261,7 @@ int image_run(nxc_handle *h, int64_t p, const T *dx, const T *dy, const T *dz, c
                        h->d_image, h->d_ctr);
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
 }
 
@@ -1260,12 +1357,13 @@ int nxc_destroy(nxc_handle *h)
         g_handles.erase(std::remove(g_handles.begin(), g_handles.end(), h), g_handles.end());
     }
     (void)hipSetDevice(h->device);
+    if (h->stream) (void)stream_sync(h);          // bounded when a collective is still in flight
+    g_coll_failure.clear();
     if (h->comm && g_rccl.ok) g_rccl.CommDestroy(h->comm);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
                     h->d_source, h->d_queue, h->d_samples, h->d_tiles, h->d_hist, h->d_rec, h->d_piece_hist,
-                    h->d_blob_img};
+                    h->d_blob_img, h->d_reduce_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     pool_flush(h);
@@ -1310,7 +1408,7 @@ int nxc_synchronize(nxc_handle *h)
 {
     if (!h) return fail(NXC_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
 }
 
@@ -1449,7 +1547,7 @@ int nxc_set_bounce(nxc_handle *h, const nxc_bounce_desc *d)
     if (h->d_blob)
         HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, B), &h->header.B, sizeof(BounceK),
                               hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1494,7 +1592,7 @@ int nxc_set_bodies(nxc_handle *h, const nxc_bodies_desc *d)
     if (h->d_blob)
         HIPCHK(hipMemcpyAsync(h->d_blob + offsetof(LdsHeader, Bd), &h->header.Bd, sizeof(BodyK),
                               hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1539,7 +1637,7 @@ int nxc_image_download(nxc_handle *h, double *image, uint64_t *counts)
     std::vector<double> both(2 * h->npix);
     HIPCHK(hipMemcpyAsync(both.data(), h->d_image, 2 * h->npix * sizeof(double),
                           hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     for (size_t q = 0; q < h->npix; q++) {
         if (image) image[q] = both[2 * q];
         if (counts) counts[q] = (uint64_t)both[2 * q + 1];      // integer-valued, < 2^53
@@ -1565,7 +1663,7 @@ int nxc_counters_get(nxc_handle *h, nxc_counters *out)
     HIPCHK(hipSetDevice(h->device));
     DevCounters c;
     HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     out->particle_steps = c.particle_steps;
     out->samples = c.samples;
     out->samples_binned = c.samples_binned;
@@ -1612,7 +1710,7 @@ int nxc_state(nxc_handle *h, int64_t n, const double *x, const double *y, const 
     double *dst[4] = {ax, ay, az, ioniz};
     for (int c = 0; c < 4; c++)
         HIPCHK(hipMemcpyAsync(dst[c], d + (4 + c) * n, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1648,7 +1746,7 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
     HIPCHK(hipMemcpyAsync(soa_out, d_out, 8 * col, hipMemcpyDeviceToHost, h->stream));
     if (delta_out)
         HIPCHK(hipMemcpyAsync(delta_out, d_delta, 8 * col, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1722,7 +1820,7 @@ static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifet
     if ((rc = order_async(h, h->stream, h->d_packets, n, n, d_lifetimes, scale, d_max, h->d_hist,
                           h->d_order, h->d_queue, false)))
         return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     h->have_order = true;
     return NXC_OK;
 }
@@ -1742,7 +1840,7 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     // Queue order for the persistent kernels (longest-lived first): counting sort of the packet
     // indices by decreasing |v|^2 on the device, bounded by the largest launch speed found there.
     if ((rc = order_on_device(h, -1.0, nullptr, 0))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1806,7 +1904,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
             const std::vector<u128> maps = pcg_tables(inc, d->pcg_n);
             HIPCHK(hipMemcpyAsync(h->d_source, maps.data(), maps.size() * sizeof(u128),
                                   hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));      // the table is a local
+            HIPCHK(stream_sync(h));      // the table is a local
         }
         if (n_sp) {
             HIPCHK(hipMemcpyAsync(h->d_source, d->speed_cdf, n_sp * 8, hipMemcpyHostToDevice, h->stream));
@@ -1851,7 +1949,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     if ((rc = end_timed(h))) return rc;
     DevCounters c;
     HIPCHK(hipMemcpyAsync(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     if (c.unfinished) {
         h->n_packets = 0;            // never-accepted candidates must not pass for packets
         h->have_order = false;
@@ -1867,7 +1965,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
         HIPCHK(hipMemcpy2DAsync(soa_out, (size_t)n * 8, h->d_packets + offset, (size_t)total * 8,
                                 (size_t)n * 8, 8, hipMemcpyDeviceToHost, h->stream));
     if (offset + n < total) {        // more pieces to come: the queue order waits for the last
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(stream_sync(h));
         return NXC_OK;
     }
     double vmax;
@@ -1881,7 +1979,7 @@ int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, doubl
     }
     // (a set made of pieces may mix sources: let the device find its largest launch speed)
     if ((rc = order_on_device(h, d->dest_total > 0 ? -1.0 : vmax * vmax, nullptr, 0))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -1958,7 +2056,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
     auto give_up = [&](int code) {
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, h->stream2, d_avail, ~0ull);
         (void)hipStreamSynchronize(h->stream2);
-        (void)hipStreamSynchronize(h->stream);
+        (void)stream_sync(h);
         h->n_packets = 0;
         return code;
     };
@@ -1983,7 +2081,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         unsigned long long *hist = h->d_piece_hist + (size_t)p * per_piece, *d_max = hist + NXC_ORDER_BINS;
         if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, sizeof(unsigned long long), h->stream2);
         if (e != hipSuccess)
-            return give_up(fail(NXC_ERR_HIP, std::string("streamed upload: ") + hipGetErrorString(e)));
+            return give_up(fail_hip("streamed upload", e));
         hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, len, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
                            h->stream2, (const double *)(h->d_packets + p0), n, len, d_max);
         if ((rc = order_async(h, h->stream2, h->d_packets + p0, n, len, nullptr, 0.0, d_max, hist,
@@ -2050,7 +2148,7 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
         // the caller's counters are those of pass 1 (work, samples); pass 2 re-does the steps
         DevCounters pass1;
         HIPCHK(hipMemcpyAsync(&pass1, h->d_ctr, sizeof pass1, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(stream_sync(h));
         d_final = h->d_scratch;
         d_steps = h->d_steps;
         if ((rc = write_records(h, false, tbytes))) return rc;
@@ -2071,22 +2169,22 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
             e = hipMemcpyAsync(&pass2, h->d_ctr, sizeof pass2, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(traj_out, d_traj, tbytes, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = stream_sync(h);
         if (e == hipSuccess) {
             pass1.unfinished += pass2.unfinished;        // rows the two passes disagree on
             e = hipMemcpyAsync(h->d_ctr, &pass1, sizeof pass1, hipMemcpyHostToDevice, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = stream_sync(h);
         }
         if (d_traj) (void)hipFree(d_traj);
         if (e != hipSuccess)
-            return fail(NXC_ERR_HIP, std::string("trajectory run: ") + hipGetErrorString(e));
+            return fail_hip("trajectory run", e);
     }
     if (final_out)
         HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));
     if (steps_out)
         HIPCHK(hipMemcpyAsync(steps_out, d_steps, (size_t)n * sizeof(long long),
                               hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -2128,7 +2226,7 @@ int nxc_rows_free(nxc_handle *h, nxc_rows *r)
 {
     if (!r) return NXC_OK;
     (void)hipSetDevice(r->device);
-    if (h && h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h && h->stream) (void)stream_sync(h);
     if (h && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h && h->device == r->device) {
         pool_give(h, r->d_cols, r->cols_cap);
@@ -2257,7 +2355,7 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));
     if (hstore_out)
         HIPCHK(hipMemcpyAsync(hstore_out, d_hs, col, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -2332,6 +2430,12 @@ int nxc_comm_init(nxc_handle *h, const uint8_t id[NXC_UNIQUE_ID_BYTES], int rank
     }
     h->rank = rank;
     h->nranks = nranks;
+    h->coll_pending = false;
+    h->abort_requested.store(false);
+    if (const char *t = std::getenv("NXC_COLLECTIVE_TIMEOUT_S")) {
+        const double v = std::atof(t);
+        if (v > 0.0) h->coll_timeout_s = v;
+    }
     return NXC_OK;
 }
 
@@ -2348,32 +2452,101 @@ int nxc_comm_destroy(nxc_handle *h)
     return NXC_OK;
 }
 
+int nxc_comm_set_timeout(nxc_handle *h, double seconds)
+{
+    if (!h || !(seconds > 0.0)) return fail(NXC_ERR_ARG, "bad arguments");
+    h->coll_timeout_s = seconds;
+    return NXC_OK;
+}
+
+int nxc_comm_request_abort(nxc_handle *h)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    h->abort_requested.store(true);
+    return NXC_OK;
+}
+
+int nxc_comm_test_stall(nxc_handle *h, double seconds)
+{
+    if (!h || !(seconds >= 0.0) || seconds > 30.0) return fail(NXC_ERR_ARG, "bad arguments");
+    if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, h->stream,
+                       (unsigned long long)(seconds * 1e8), (unsigned long long *)nullptr);
+    HIPCHK(hipGetLastError());
+    h->coll_pending = true;
+    return NXC_OK;
+}
+
+// A rank that has been told of a peer's failure does not enter another collective.
+static int refuse_after_abort_request(nxc_handle *h)
+{
+    if (!h->abort_requested.load()) return NXC_OK;
+    if (h->comm && g_rccl.ok) (void)g_rccl.CommAbort(h->comm);
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    h->coll_pending = false;
+    return fail(NXC_ERR_RCCL, "a peer rank reported a failure; the communicator was aborted");
+}
+
+int nxc_comm_abort(nxc_handle *h)
+{
+    if (!h) return fail(NXC_ERR_ARG, "null handle");
+    if (h->comm && g_rccl.ok) {
+        (void)hipSetDevice(h->device);
+        (void)g_rccl.CommAbort(h->comm);
+    }
+    h->comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    h->coll_pending = false;
+    return NXC_OK;
+}
+
 int nxc_image_allreduce(nxc_handle *h)
 {
     if (!h || !h->have_image) return fail(NXC_ERR_STATE, "nxc_set_image has not been called");
     if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
+    if (int rc = refuse_after_abort_request(h)) return rc;
     // one collective: weights and (integer-valued fp64) counts are interleaved in one array
+    h->coll_pending = true;
     NCCLCHK(g_rccl.AllReduce(h->d_image, h->d_image, 2 * h->npix, ncclFloat64, ncclSum, h->comm,
                              h->stream));
     return NXC_OK;
 }
 
-static int allreduce_scalar(nxc_handle *h, double *value, ncclRedOp_t op)
+// In-place all-reduce of n host doubles (n small: scalars of the bench, the S radiances + S
+// packet counts of a set of lines of sight): staged through device scratch on the handle's stream.
+static int allreduce_host(nxc_handle *h, double *values, int64_t n, ncclRedOp_t op)
 {
-    if (!h || !value) return fail(NXC_ERR_ARG, "null argument");
+    if (!h || !values || n < 1) return fail(NXC_ERR_ARG, "bad arguments");
     if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(h->d_reduce, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    NCCLCHK(g_rccl.AllReduce(h->d_reduce, h->d_reduce, 1, ncclFloat64, op, h->comm, h->stream));
-    HIPCHK(hipMemcpyAsync(value, h->d_reduce, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    double *d = h->d_reduce;
+    if (n > 1) {
+        int rc = ensure(reinterpret_cast<void **>(&h->d_reduce_n), &h->reduce_n_cap, (size_t)n * 8);
+        if (rc) return rc;
+        d = h->d_reduce_n;
+    }
+    if (int rc = refuse_after_abort_request(h)) return rc;
+    HIPCHK(hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    h->coll_pending = true;
+    NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, op, h->comm, h->stream));
+    HIPCHK(hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
 }
 
-int nxc_allreduce_max_f64(nxc_handle *h, double *value) { return allreduce_scalar(h, value, ncclMax); }
+int nxc_allreduce_max_f64(nxc_handle *h, double *value) { return allreduce_host(h, value, 1, ncclMax); }
 
-int nxc_allreduce_sum_f64(nxc_handle *h, double *value) { return allreduce_scalar(h, value, ncclSum); }
+int nxc_allreduce_sum_f64(nxc_handle *h, double *value) { return allreduce_host(h, value, 1, ncclSum); }
+
+int nxc_allreduce_f64(nxc_handle *h, double *values, int64_t n)
+{
+    return allreduce_host(h, values, n, ncclSum);
+}
 
 int nxc_barrier(nxc_handle *h)
 {
@@ -2409,7 +2582,7 @@ int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs)
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);
     (void)hipFree(buf);
-    if (e != hipSuccess) return fail(NXC_ERR_HIP, std::string("stream copy: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail_hip("stream copy", e);
     *gbs = 2.0 * (double)n16 * 16.0 / ((double)best * 1e-3) / 1e9;      // bytes read + written
     return NXC_OK;
     });
@@ -2433,7 +2606,7 @@ int nxc_shader_clock_mhz(nxc_handle *h, double *mhz)
     }
     HIPCHK(hipMemcpyAsync(got.data(), d, got.size() * sizeof(unsigned long long),
                           hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     std::vector<double> f;
     for (int w = 0; w < waves; w++)
         if (got[3 * (size_t)w + 1] > 0)
@@ -2467,7 +2640,7 @@ int nxc_pcg64_uniforms(nxc_handle *h, const uint64_t state[2], const uint64_t in
                        h->stream, P, (int)nvec, count, reinterpret_cast<double *>(base + map_bytes));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, base + map_bytes, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }
@@ -2491,7 +2664,7 @@ int nxc_math_batch(nxc_handle *h, int which, int64_t n, const double *in, const 
                        h->d_blob, which, n, d, d + n, d + 2 * n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d + 2 * n, col, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(stream_sync(h));
     return NXC_OK;
     });
 }

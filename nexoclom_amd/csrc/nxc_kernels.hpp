@@ -1085,6 +1085,21 @@ k_clock(unsigned long long *__restrict__ out, int iters, double seed)
     }
 }
 
+// Fault injection for the bounded wait on a collective (nxc_comm_test_stall): one wave that holds
+// the stream for `ticks` of the 100 MHz s_memrealtime counter and then leaves -- it ends by itself
+// whether or not anybody still waits for it.
+__global__ void __launch_bounds__(64)
+k_stall(unsigned long long ticks, unsigned long long *__restrict__ out)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long now = t0;
+    while (now - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(127);
+        now = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0 && out) *out = now - t0;
+}
+
 __global__ void k_math(const unsigned char *__restrict__ blob, int which, int64_t n,
                        const double *__restrict__ in, const double *__restrict__ in2,
                        double *__restrict__ out)

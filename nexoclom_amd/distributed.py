@@ -25,7 +25,9 @@ import os
 import secrets
 import socket
 import struct
+import select
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -91,6 +93,14 @@ class ControlPlane:
     store owns that port, so it is used only as a job identifier); the other ranks poll the file,
     connect and prove the token.  Every method is a collective: all ranks must call it, in the
     same order.  Trivial when world == 1.
+
+    Failure detection: every rank keeps a SECOND connection to rank 0 that carries nothing but
+    goodbyes.  ``watch(callback)`` starts a daemon thread on it: a rank that fails calls
+    ``announce_failure`` (or simply dies -- the kernel closes its socket), rank 0 tells everybody,
+    and every rank's ``callback(reason)`` runs within milliseconds -- ``sharded`` code passes
+    ``ctx.comm_request_abort`` so that a rank waiting inside an RCCL collective leaves it at once
+    instead of at the collective deadline (hip_api.Context.comm_set_timeout).  ``close()`` says an
+    orderly goodbye first, so a rank that merely finishes early raises no alarm.
     """
 
     def __init__(self, world=None, rank=None, timeout=300.0, rendezvous=None):
@@ -101,6 +111,11 @@ class ControlPlane:
         self.timeout = float(timeout)
         self._peers = {}           # rank 0: rank -> socket
         self._root = None          # other ranks: socket to rank 0
+        self._watch_peers = {}     # rank 0: rank -> failure-channel socket
+        self._watch_root = None    # other ranks: failure-channel socket to rank 0
+        self._watcher = None
+        self._lock = threading.Lock()
+        self.failure = None        # the reason, once a peer's failure is known
         self._file = None
         if not 0 <= self.rank < self.world:
             raise ValueError(f'rank {self.rank} outside world of {self.world}')
@@ -130,23 +145,27 @@ class ControlPlane:
             f.write(f'{srv.getsockname()[1]} {token}\n')
         os.replace(tmp, self._file)               # atomic: readers see old or new, never half
         try:
-            while len(self._peers) < self.world - 1:
+            while len(self._peers) + len(self._watch_peers) < 2*(self.world - 1):
                 conn, _ = srv.accept()
                 conn.settimeout(5.0)             # a stranger on the port must not stall the job
                 try:
                     hello = _recv(conn)
-                    magic, tok, r = hello[:5], hello[5:37].decode(), struct.unpack('<I', hello[37:41])[0]
-                    if magic != _MAGIC or tok != token or not 0 < r < self.world or r in self._peers:
+                    magic, tok = hello[:5], hello[5:37].decode()
+                    r, channel = struct.unpack('<II', hello[37:45])
+                    table = (self._peers, self._watch_peers)[channel]
+                    if magic != _MAGIC or tok != token or not 0 < r < self.world or r in table:
                         raise ConnectionError('bad hello')
-                except (ConnectionError, OSError, struct.error, UnicodeDecodeError, MemoryError):
+                except (ConnectionError, OSError, struct.error, UnicodeDecodeError, MemoryError,
+                        IndexError):
                     conn.close()
                     continue
-                conn.settimeout(self.timeout)
+                conn.settimeout(self.timeout if channel == 0 else None)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 _send(conn, _MAGIC + token.encode())
-                self._peers[r] = conn
+                table[r] = conn
         except socket.timeout:
-            raise TimeoutError(f'control plane: only {len(self._peers) + 1} of {self.world} '
+            arrived = len(set(self._peers) & set(self._watch_peers)) + 1
+            raise TimeoutError(f'control plane: only {arrived} of {self.world} '
                                f'ranks arrived within {self.timeout:.0f} s') from None
         finally:
             srv.close()
@@ -161,15 +180,21 @@ class ControlPlane:
             try:
                 with open(self._file) as f:
                     port, token = f.read().split()
-                sock = socket.create_connection(('127.0.0.1', int(port)), timeout=5.0)
-                sock.settimeout(self.timeout)
-                _send(sock, _MAGIC + token.encode() + struct.pack('<I', self.rank))
-                if _recv(sock) != _MAGIC + token.encode():
-                    raise ConnectionError('bad reply')
-                sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                self._root = sock
+                socks = []
+                for channel in (0, 1):
+                    sock = socket.create_connection(('127.0.0.1', int(port)), timeout=5.0)
+                    socks.append(sock)
+                    sock.settimeout(self.timeout)
+                    _send(sock, _MAGIC + token.encode() + struct.pack('<II', self.rank, channel))
+                    if _recv(sock) != _MAGIC + token.encode():
+                        raise ConnectionError('bad reply')
+                    sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self._root, self._watch_root = socks
+                self._watch_root.settimeout(None)
                 return
             except (OSError, ValueError, ConnectionError):
+                for sock in locals().get('socks', ()):
+                    sock.close()
                 # no file yet, a stale file of an earlier job, or a foreign listener: look again
                 if time.monotonic() > deadline:
                     raise TimeoutError(f'control plane: rank {self.rank} found no rank 0 via '
@@ -283,13 +308,104 @@ class ControlPlane:
                 pass
             raise hip_api.HipError(f'RCCL communicator could not be created ({verdict})')
 
+    # -- failure detection --------------------------------------------------------------------
+    def watch(self, callback):
+        """Start the failure watcher: ``callback(reason)`` runs (once, on a daemon thread) as soon
+        as any rank announces a failure or disappears without a goodbye."""
+        if self.world == 1 or self._watcher is not None:
+            return
+        self._watcher = threading.Thread(target=self._watch_loop, args=(callback,), daemon=True,
+                                         name='nexoclom-failure-watch')
+        self._watcher.start()
+
+    def _alarm(self, reason, callback):
+        with self._lock:
+            first, self.failure = self.failure is None, self.failure or reason
+        if first and callback is not None:
+            try:
+                callback(self.failure)
+            except Exception:                      # a watcher must not die of its callback
+                pass
+
+    def _watch_loop(self, callback):
+        if self.rank != 0:
+            sock = self._watch_root
+            try:
+                msg = sock.recv(256)
+            except OSError:
+                msg = b''
+            if msg[:1] == b'B' or self._closing:
+                return                              # rank 0 finished in good order
+            self._alarm(msg[1:].decode(errors='replace') if msg[:1] == b'X'
+                        else 'rank 0 is gone', callback)
+            return
+        live = dict(self._watch_peers)
+        while live and not self._closing:
+            try:
+                ready, _, _ = select.select(list(live.values()), [], [], 0.25)
+            except (OSError, ValueError):
+                return
+            for sock in ready:
+                r = next(k for k, v in live.items() if v is sock)
+                try:
+                    msg = sock.recv(256)
+                except OSError:
+                    msg = b''
+                del live[r]
+                if msg[:1] == b'B':
+                    continue                        # rank r finished in good order
+                reason = (msg[1:].decode(errors='replace') if msg[:1] == b'X'
+                          else f'rank {r} is gone (its process ended without a goodbye)')
+                self._tell_all(b'X' + reason.encode()[:200])
+                self._alarm(reason, callback)
+                return
+
+    def _tell_all(self, msg):
+        for sock in self._watch_peers.values():
+            try:
+                sock.sendall(msg)
+            except OSError:
+                pass
+
+    def announce_failure(self, reason):
+        """This rank cannot go on: every other rank's watcher is told (through rank 0)."""
+        if self.world == 1:
+            return
+        msg = b'X' + f'rank {self.rank}: {reason}'.encode()[:200]
+        with self._lock:
+            self.failure = self.failure or f'rank {self.rank}: {reason}'
+        if self.rank == 0:
+            self._tell_all(msg)
+        elif self._watch_root is not None:
+            try:
+                self._watch_root.sendall(msg)
+            except OSError:
+                pass
+
+    _closing = False
+
     def close(self):
-        for s in list(self._peers.values()) + ([self._root] if self._root else []):
+        self._closing = True
+        if self.failure is None:                   # an orderly goodbye raises no alarm
+            if self.rank == 0:
+                self._tell_all(b'B')
+            elif self._watch_root is not None:
+                try:
+                    self._watch_root.sendall(b'B')
+                except OSError:
+                    pass
+        socks = list(self._peers.values()) + list(self._watch_peers.values())
+        socks += [s for s in (self._root, self._watch_root) if s is not None]
+        for s in socks:
+            try:
+                s.shutdown(socket.SHUT_RDWR)
+            except OSError:
+                pass
             try:
                 s.close()
             except OSError:
                 pass
-        self._peers, self._root = {}, None
+        self._peers, self._root, self._watch_peers, self._watch_root = {}, None, {}, None
 
 
 # ---- sharded run -----------------------------------------------------------------------------
@@ -308,6 +424,33 @@ def pick_device(cp, device=None):
         raise hip_api.HipError(f'rank {cp.rank}: device {dev} does not exist ({ndev} visible); '
                                'launch one process per GPU')
     return dev
+
+
+class guarded:
+    """``with guarded(cp, ctx):`` around a sharded computation -- no rank can hang the others.
+    The control plane's failure watcher ends this rank's wait on a collective as soon as a peer
+    fails (``ctx.comm_request_abort``; past that, the collective deadline of
+    hip_api.Context.comm_set_timeout holds); an exception raised in the block is announced to the
+    peers before it propagates."""
+
+    def __init__(self, cp, ctx):
+        self.cp, self.ctx = cp, ctx
+
+    def __enter__(self):
+        if hasattr(self.cp, 'watch') and hasattr(self.ctx, 'comm_request_abort'):
+            self.cp.watch(lambda reason: self.ctx.comm_request_abort())
+        return self
+
+    def __exit__(self, kind, exc, tb):
+        if exc is not None and isinstance(exc, Exception):
+            if hasattr(self.cp, 'announce_failure'):
+                self.cp.announce_failure(f'{kind.__name__}: {exc}')
+            if hasattr(self.ctx, 'comm_abort'):
+                try:
+                    self.ctx.comm_abort()
+                except Exception:                   # noqa: BLE001 -- the first error is the news
+                    pass
+        return False
 
 
 def merge_shards(img, cp, ctx, reduce='rccl'):
@@ -348,14 +491,15 @@ def sharded_image(inputs, params, npackets, seed, cp=None, device=None, downcast
     if context is None:
         from . import hip_api
         context = hip_api.Context(pick_device(cp, device))
-    if seed is None and sampler == 'device':
-        # an unseeded run still is ONE run: every rank uses rank 0's fresh key
-        from .Output import fresh_key
-        seed = int.from_bytes(cp.bcast_bytes(fresh_key().to_bytes(8, 'little'), 8), 'little')
-    lo, hi = shard_range(int(npackets), cp.rank, cp.world)
-    img = ModelImage(inputs, params, npackets=int(npackets), shard=(lo, hi), seed=seed,
-                     context=context, downcast=downcast, sampler=sampler,
-                     packs_per_it=packs_per_it, finalize=False)
-    merge_shards(img, cp, context, reduce)
-    img.finalize()
+    with guarded(cp, context):
+        if seed is None and sampler == 'device':
+            # an unseeded run still is ONE run: every rank uses rank 0's fresh key
+            from .Output import fresh_key
+            seed = int.from_bytes(cp.bcast_bytes(fresh_key().to_bytes(8, 'little'), 8), 'little')
+        lo, hi = shard_range(int(npackets), cp.rank, cp.world)
+        img = ModelImage(inputs, params, npackets=int(npackets), shard=(lo, hi), seed=seed,
+                         context=context, downcast=downcast, sampler=sampler,
+                         packs_per_it=packs_per_it, finalize=False)
+        merge_shards(img, cp, context, reduce)
+        img.finalize()
     return img

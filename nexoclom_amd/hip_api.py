@@ -33,12 +33,22 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_allreduce_sum_f64', 'nxc_rows_build', 'nxc_rows_info', 'nxc_rows_download',
            'nxc_rows_free', 'nxc_image_accumulate_rows', 'nxc_los_accumulate_rows', 'nxc_mem_info',
            'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms',
-           'nxc_integrate_const_streamed', 'nxc_image_mode')
+           'nxc_integrate_const_streamed', 'nxc_image_mode', 'nxc_allreduce_f64',
+           'nxc_comm_set_timeout', 'nxc_comm_abort', 'nxc_comm_request_abort',
+           'nxc_comm_test_stall')
 ABI_VERSION = 2
 
 
+NXC_ERR_HIP, NXC_ERR_ARG, NXC_ERR_NO_DEVICE, NXC_ERR_RCCL, NXC_ERR_STATE, NXC_ERR_NOMEM = \
+    -1, -2, -3, -4, -5, -6
+
+
 class HipError(RuntimeError):
-    pass
+    """An nxc_* call failed; ``code`` is its NXC_ERR_* status (None when raised by the binding)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class nxc_forces(C.Structure):
@@ -216,7 +226,7 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             msg = self.lib.nxc_last_error_string()
-            raise HipError(f'nexoclom_hip error {rc}: {msg.decode() if msg else "?"}')
+            raise HipError(f'nexoclom_hip error {rc}: {msg.decode() if msg else "?"}', rc)
 
     def make_room(self, need):
         """Before ``need`` bytes of row store (+ scratch) are allocated: spill the oldest resident
@@ -646,6 +656,31 @@ class Context:
 
     def barrier(self):
         self._check(self.lib.nxc_barrier(self._h))
+
+    def allreduce(self, values):
+        """Sum over the ranks of a small float64 array (returned; LOSResult.py:264-266 across
+        GPUs)."""
+        v = np.array(values, dtype=np.float64).ravel()
+        self._check(self.lib.nxc_allreduce_f64(self._h, _p(v), C.c_int64(v.size)))
+        return v.reshape(np.shape(values))
+
+    def comm_set_timeout(self, seconds):
+        """Deadline of every wait on a collective (default 120 s): past it the communicator is
+        aborted and the waiting call raises HipError (code NXC_ERR_RCCL)."""
+        self._check(self.lib.nxc_comm_set_timeout(self._h, C.c_double(seconds)))
+
+    def comm_abort(self):
+        self._check(self.lib.nxc_comm_abort(self._h))
+
+    def comm_request_abort(self):
+        """Thread-safe: ends the owning thread's wait on a collective (or its next collective)
+        with HipError instead of letting it run to the deadline."""
+        if self._h:
+            self.lib.nxc_comm_request_abort(self._h)
+
+    def comm_test_stall(self, seconds):
+        """Fault injection: the stream is busy for ``seconds`` as if a collective hung."""
+        self._check(self.lib.nxc_comm_test_stall(self._h, C.c_double(seconds)))
 
     # -- measurement helpers ----------------------------------------------------------------
     def stream_copy_gbs(self, nbytes=1 << 31, reps=5):

@@ -31,6 +31,7 @@ class OracleContext:
         self._ctr = {}
         self.calls = []                    # (n_packets, first_index) of every integrate call
         self._first = 0
+        self.abort_requested = False
 
     # -- set-up -----------------------------------------------------------------------------
     def set_forces(self, GM, vrplanet, gravity=True, radpres=True, lifetime=0.0, photo=None,
@@ -113,6 +114,19 @@ class OracleContext:
 
     def comm_destroy(self):
         self.log.append('comm_destroy')
+
+    def comm_abort(self):
+        self.log.append('comm_abort')
+
+    def comm_request_abort(self):          # called from the control plane's watcher thread
+        self.abort_requested = True
+
+    def comm_set_timeout(self, seconds):
+        self.log.append('comm_set_timeout')
+
+    def allreduce(self, values):
+        self.log.append('allreduce')
+        return self.cp.allreduce(np.asarray(values, dtype=np.float64))
 
     def image_allreduce(self):
         self.log.append('image_allreduce')

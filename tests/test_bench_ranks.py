@@ -16,20 +16,34 @@ ARGV = ['--packets', '1500', '--steps', '2', '--warmup', '1', '--dims', '64', '-
         '--no-cpu-baseline']
 
 
-def _worker(rank, world, port, tmpdir, broken_rank):
+def _worker(rank, world, port, tmpdir, broken_rank, fault):
+    """fault: None | 'no-device' (make_context raises on broken_rank) | 'raise' (its second pass
+    raises) | 'die' (its second pass ends the process without a word)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import bench
     from nexoclom_amd import hip_api
-    from nexoclom_amd.distributed import ControlPlane
+    from nexoclom_amd.distributed import ControlPlane, pick_device
     from tests.oracle_context import OracleContext
     args = bench.parse(ARGV)
-    cp = ControlPlane(world, rank, timeout=120)
-    ctx = OracleContext(cp=cp, seat=f'oracle:{rank}')
+    cp = ControlPlane(world, rank, timeout=60)
+    # the device pick of a node with one GPU per rank: LOCAL_RANK of `world` visible devices
+    real_count, hip_api.device_count = hip_api.device_count, lambda: world
+    assert pick_device(cp) == rank
+    hip_api.device_count = real_count
+
+    class Ctx(OracleContext):
+        def integrate_const_async(self, *a, **k):
+            if rank == broken_rank and fault in ('raise', 'die') and len(self.calls) == 1:
+                if fault == 'die':
+                    os._exit(3)
+                raise RuntimeError('device lost in the middle of pass 2')
+            return super().integrate_const_async(*a, **k)
+    ctx = Ctx(cp=cp, seat=f'0000:{rank:02x}:00.0', threads=1)
 
     def make_context():
-        if rank == broken_rank:
+        if rank == broken_rank and fault == 'no-device':
             raise hip_api.HipError(f'rank {rank}: device {rank} does not exist (1 visible)')
         return ctx
     lines = []
@@ -40,20 +54,31 @@ def _worker(rank, world, port, tmpdir, broken_rank):
     json.dump(out, open(os.path.join(tmpdir, f'rank{rank}.json'), 'w'))
 
 
-def _run(tmp_path, broken_rank=-1, world=2):
+def _run(tmp_path, broken_rank=-1, world=2, fault=None, limit=600):
+    import time
     port = 29900 + os.getpid() % 300
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), broken_rank))
+    if broken_rank >= 0 and fault is None:
+        fault = 'no-device'
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), broken_rank, fault))
              for r in range(world)]
+    t0 = time.monotonic()
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
+        p.join(max(1.0, limit - (time.monotonic() - t0)))
+    hung = [r for r, p in enumerate(procs) if p.is_alive()]
     for p in procs:
         if p.is_alive():
             p.kill()
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    return [json.load(open(tmp_path / f'rank{r}.json')) for r in range(world)]
+    assert not hung, f'ranks {hung} were still waiting after {limit} s'
+    codes = [p.exitcode for p in procs]
+    if fault == 'die':
+        assert codes[broken_rank] == 3 and all(c == 0 for r, c in enumerate(codes) if r != broken_rank), codes
+    else:
+        assert all(c == 0 for c in codes), codes
+    return [json.load(open(tmp_path / f'rank{r}.json')) if (tmp_path / f'rank{r}.json').exists()
+            else None for r in range(world)]
 
 
 def test_two_ranks_run_the_whole_bench_logic(tmp_path):
@@ -117,3 +142,49 @@ def test_with_comm_on_one_rank_takes_the_collective_branches(tmp_path, capsys):
     # warmup + timed + incl-H2D passes reduce the image; the plain comparison passes do not
     assert ctx.log.count('image_allreduce') == 1 + 2 + 2 and len(ctx.calls) == 1 + 2 + 2 + 2
     assert ctx.log.count('comm_init') == ctx.log.count('comm_destroy') == 1
+
+
+def test_eight_ranks_run_the_whole_bench_logic(tmp_path):
+    """The driver's scaling run is a world of EIGHT: same code, eight seats, eight shards."""
+    res = _run(tmp_path, world=8)
+    assert [r['rc'] for r in res] == [0]*8
+    assert len(res[0]['lines']) == 1 and all(r['lines'] == [] for r in res[1:])
+    line = json.loads(res[0]['lines'][0])
+    passes = 1 + 2 + 2
+    for rank, r in enumerate(res):
+        assert r['calls'] == [[1500, 1500*rank]]*passes           # shard = chunk `rank`
+        assert r['log'].count('image_allreduce') == passes
+        assert r['log'][-2:] == ['comm_destroy', 'close']
+        assert r['counts_sum'] == sum(x['binned'] for x in res)   # everybody holds the global image
+    assert len({r['work'] for r in res}) == 8                     # eight different packet sets
+    assert line['n_gpus'] == 8 and line['config']['parallelism'] == 'packet-shard x8'
+    assert line['particle_steps_per_pass'] == sum(r['work'] for r in res)
+    np.testing.assert_allclose(line['value'],
+                               line['particle_steps_per_pass']/(line['ms_per_step']*1e-3))
+
+
+def test_a_rank_that_raises_mid_pass_ends_all_eight_ranks_with_a_failure_line(tmp_path):
+    """Rank 5 raises inside its second pass while the others wait in that pass's image
+    all-reduce: the failure channel of the control plane ends every wait, rank 0 prints the
+    `"value": null` line naming rank 5's error, every rank returns 1 -- in seconds, not at a
+    job limit."""
+    import time
+    t0 = time.monotonic()
+    res = _run(tmp_path, broken_rank=5, world=8, fault='raise', limit=120)
+    assert time.monotonic() - t0 < 120
+    assert [r['rc'] for r in res] == [1]*8
+    line = json.loads(res[0]['lines'][0])
+    assert line['value'] is None and line['n_gpus'] == 8
+    assert 'rank 5' in line['error'] and 'device lost in the middle of pass 2' in line['error']
+    assert all(r['lines'] == [] for r in res[1:])
+    assert 'comm_abort' in res[5]['log']
+
+
+def test_a_rank_that_dies_mid_pass_ends_all_eight_ranks_with_a_failure_line(tmp_path):
+    """The same when rank 5's process simply ends (an OOM kill): no goodbye, the closed socket
+    is the signal."""
+    res = _run(tmp_path, broken_rank=5, world=8, fault='die', limit=120)
+    assert res[5] is None
+    assert [r['rc'] for r in res if r is not None] == [1]*7
+    line = json.loads(res[0]['lines'][0])
+    assert line['value'] is None and 'rank 5' in line['error']

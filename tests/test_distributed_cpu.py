@@ -114,6 +114,84 @@ def _run(kind, tmp_path, world=2):
     assert (tmp_path / 'ok').exists()
 
 
+def _worker8(rank, world, port, tmpdir, broken):
+    """World of eight through sharded_image: every rank integrates its index range, everybody ends
+    with the global image.  broken >= 0: that rank's device fails inside its shard."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    import json
+    from nexoclom_amd import Input
+    from nexoclom_amd.distributed import ControlPlane, shard_range, sharded_image
+    from tests.oracle_context import OracleContext
+
+    class Ctx(OracleContext):
+        def integrate_const(self, *a, **k):
+            if rank == broken:
+                raise RuntimeError('device lost inside the shard')
+            return super().integrate_const(*a, **k)
+    cp = ControlPlane(world, rank, timeout=60)
+    inputs = Input(INPUT)
+    ctx = Ctx(threads=1)
+    verdict = {'rank': rank}
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            part = sharded_image(inputs, PARAMS, N, SEED, cp=cp, context=ctx, sampler='device',
+                                 packs_per_it=CHUNK, reduce='host')
+        lo, hi = shard_range(N, rank, world)
+        assert sum(n for n, _ in ctx.calls) == hi - lo and ctx.calls[0][1] == lo
+        verdict.update(ok=True, counts=float(part.packet_image.sum()), npackets=part.npackets)
+        if rank == 0:
+            one = OracleContext()
+            with contextlib.redirect_stdout(io.StringIO()):
+                whole = sharded_image(inputs, PARAMS, N, SEED, cp=ControlPlane(1, 0), context=one,
+                                      sampler='device', packs_per_it=CHUNK, reduce='host')
+            assert np.array_equal(whole.packet_image, part.packet_image)
+            np.testing.assert_allclose(part.image, whole.image, rtol=1e-12, atol=0)
+            assert whole.totalsource == part.totalsource
+    except Exception as exc:                        # noqa: BLE001 -- the verdict is the test
+        verdict.update(ok=False, error=f'{type(exc).__name__}: {exc}', peer=cp.failure)
+    cp.close()
+    json.dump(verdict, open(os.path.join(tmpdir, f'v{rank}.json'), 'w'))
+
+
+def _run8(tmp_path, broken=-1, limit=300):
+    import json
+    port = 29100 + os.getpid() % 300
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, str(tmp_path), broken))
+             for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(limit)
+    hung = [r for r, p in enumerate(procs) if p.is_alive()]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert not hung, f'ranks {hung} still waiting after {limit} s'
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [json.load(open(tmp_path / f'v{r}.json')) for r in range(8)]
+
+
+def test_eight_ranks_equal_one_rank(tmp_path):
+    res = _run8(tmp_path)
+    assert all(v['ok'] for v in res), res
+    assert len({v['counts'] for v in res}) == 1 and res[0]['counts'] > 1000
+    assert all(v['npackets'] == N for v in res)
+
+
+def test_a_failing_rank_ends_the_sharded_image_on_every_rank(tmp_path):
+    """Rank 5's device fails inside its shard: no rank is left waiting in the merge; rank 5
+    reports its own error, the others a broken collective -- and the watcher knows who it was."""
+    res = _run8(tmp_path, broken=5, limit=120)
+    assert not any(v['ok'] for v in res)
+    assert 'device lost inside the shard' in res[5]['error']
+    assert any(v['peer'] and 'rank 5' in v['peer'] for r, v in enumerate(res) if r != 5)
+
+
 def test_two_ranks_equal_one_rank_over_the_tcp_control_plane(tmp_path):
     _run('tcp', tmp_path)
 

@@ -770,7 +770,7 @@ def test_blocks_of_freed_row_stores_are_reused(ctx, coracle):
 @pytest.mark.parametrize('sampler', ['numpy', 'device', 'pcg64'])
 def test_input_run_splits_a_launch_group_whose_rows_do_not_fit(ctx, sampler, monkeypatch):
     """Input.run sizes its launch groups from an estimate of the rows per packet; when a group's
-    rows do not fit in HBM after all (NXC_ERR_ARG 'do not fit' from the rows protocol) it is split
+    rows do not fit in HBM after all (status NXC_ERR_NOMEM from the rows protocol) it is split
     in halves -- drawn again where the device draws -- and the catalogue comes out the same."""
     from nexoclom_amd import hip_api
     kw = dict(sampler='device', generator='pcg64') if sampler == 'pcg64' else dict(sampler=sampler)
@@ -784,8 +784,8 @@ def test_input_run_splits_a_launch_group_whose_rows_do_not_fit(ctx, sampler, mon
         def tight(self, *a, **k):
             calls.append(self.n_packets)
             if limit and self.n_packets > limit:
-                raise hip_api.HipError('nexoclom_hip error -2: trajectory rows do not fit in '
-                                       'device memory; run fewer packets per call')
+                raise hip_api.HipError('nexoclom_hip error -6: no room for the rows of this '
+                                       'launch group', hip_api.NXC_ERR_NOMEM)
             return real(self, *a, **k)
         monkeypatch.setattr(hip_api.Context, 'integrate_const_rows', tight)
         with contextlib.redirect_stdout(io.StringIO()):

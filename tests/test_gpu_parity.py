@@ -273,6 +273,57 @@ def test_rccl_single_rank_allreduce(ctx, coracle):
             call()
 
 
+def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
+    """nxc_comm_set_timeout: a wait on a collective is bounded.  The hang is injected
+    (nxc_comm_test_stall holds the stream as a lost peer would); the waiting call must come back
+    with NXC_ERR_RCCL near the deadline, the communicator must be gone (ncclCommAbort), and the
+    handle must stay usable once the stream has drained."""
+    import time
+    from nexoclom_amd import hip_api
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    im = H.image_setup(f, 'radiance', dims=(32, 32))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'])
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    # the healthy path goes through the same polling wait
+    ctx.image_allreduce()
+    ctx.synchronize()
+    assert ctx.allreduce(np.array([1.5, -2.0, 7.0])).tolist() == [1.5, -2.0, 7.0]
+    ctx.comm_set_timeout(0.4)
+    ctx.comm_test_stall(2.0)
+    t0 = time.perf_counter()
+    with pytest.raises(hip_api.HipError, match='did not complete within 0.4 s') as err:
+        ctx.synchronize()
+    waited = time.perf_counter() - t0
+    assert err.value.code == hip_api.NXC_ERR_RCCL and 0.35 < waited < 1.5
+    with pytest.raises(hip_api.HipError, match='nxc_comm_init'):      # no communicator any more
+        ctx.image_allreduce()
+    ctx.synchronize()                                                  # the stall ends by itself
+    assert time.perf_counter() - t0 > 1.9
+    # ... and a peer's failure reported from ANOTHER thread ends the wait at once
+    import threading
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    ctx.comm_set_timeout(30.0)
+    ctx.comm_test_stall(2.0)
+    threading.Timer(0.2, ctx.comm_request_abort).start()
+    t0 = time.perf_counter()
+    with pytest.raises(hip_api.HipError, match='peer rank reported a failure') as err:
+        ctx.synchronize()
+    assert err.value.code == hip_api.NXC_ERR_RCCL and time.perf_counter() - t0 < 1.0
+    ctx.synchronize()
+    # the handle works on: a fresh communicator, a collective, a pass
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    assert ctx.allreduce_sum(4.0) == 4.0
+    ctx.comm_destroy()
+    X0 = H.sample_x0(512, 3, 50000.)
+    ctx.upload_packets(X0)
+    nsteps, n_iter = O.n_output_steps(50000., 30.)
+    ctx.image_clear()
+    ctx.integrate_const(30., n_iter, 25., image=True)
+    assert ctx.counters()['particle_steps'] > 0
+
+
 @pytest.mark.parametrize('bounce', [False, True])
 def test_compact_rows_equal_the_filtered_dense_trajectory(ctx, coracle, bounce):
     """nxc_integrate_const_rows/nxc_rows_fetch == the frac > 0 records of the dense trajectory in
