@@ -216,11 +216,13 @@ def variable_leg(ctx, inputs_var, n, passes=3):
                          'peak': HBM_PEAK_GBS, 'achieved': ach, 'frac': ach/HBM_PEAK_GBS}}
 
 
-def stored_samples_leg(ctx, inputs, img, aplanet, vrplanet, quantity, n=1_000_000):
+def stored_samples_leg(ctx, inputs, imgs, aplanet, vrplanet, quantity, n=1_000_000):
     """a-6..a-8 over STORED samples (the reference's two-stage flow, ModelImage.py:229-274): the
     float32 rows of n packets stay in HBM (what Input.run leaves there) and are binned by k_image
     (one global atomic pair per binned sample) and by the tiled image (k_image_bin +
-    k_image_tiles); kernel time by HIP events, 40 / 32 algorithmic bytes per sample."""
+    k_image_tiles); kernel time by HIP events, 40 / 32 algorithmic bytes per sample.
+    ``imgs``: ModelImages by label -- BASELINE's 512 x 512 and the reference's default 800 x 800
+    (ModelImage.py:53) over the same rows."""
     from nexoclom_amd import Output
     from nexoclom_amd.Output import n_output_steps
     opt = inputs.options
@@ -231,36 +233,41 @@ def stored_samples_leg(ctx, inputs, img, aplanet, vrplanet, quantity, n=1_000_00
     ctx.upload_soa(out.x0_soa())
     store = ctx.integrate_const_rows(opt.step_size, n_iter, opt.outeredge, narrow=True,
                                      resident=True)['store']
-    img._set_image(ctx, aplanet, vrplanet, False)
     per_sample = 40 if quantity == 'radiance' else 32
-    leg = {'samples': int(store.total), 'quantity': quantity,
-           'algorithmic_bytes_per_sample': per_sample}
-    for mode in ('atomics', 'tiles'):
-        ctx.image_mode(mode)
-        ms = []
-        for it in range(4):
-            ctx.image_clear()
-            ctx.image_accumulate_rows(store)
-            if it:
-                ms.append(ctx.last_kernel_ms())
-        k_ms = float(np.mean(ms))
-        ach = per_sample*store.total/(k_ms*1e-3)/1e9
-        leg[mode] = {'kernel': 'k_image' if mode == 'atomics' else 'k_image_bin + k_image_tiles',
-                     'kernel_ms': k_ms, 'samples_per_s': store.total/(k_ms*1e-3),
-                     'pixels_per_s': img.dims[0]*img.dims[1]/(k_ms*1e-3),
-                     'binned': ctx.counters()['samples_binned'],
-                     'roofline': {'bound': 'atomic requests' if mode == 'atomics' else 'hbm',
-                                  'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
-                                  'frac': ach/HBM_PEAK_GBS}}
-    ctx.image_mode('auto')
+    legs = {}
+    for label, img in imgs.items():
+        img._set_image(ctx, aplanet, vrplanet, False)
+        leg = {'samples': int(store.total), 'quantity': quantity, 'image': label,
+               'algorithmic_bytes_per_sample': per_sample}
+        for mode in ('atomics', 'tiles'):
+            ctx.image_mode(mode)
+            ms = []
+            for it in range(4):
+                ctx.image_clear()
+                ctx.image_accumulate_rows(store)
+                if it:
+                    ms.append(ctx.last_kernel_ms())
+            k_ms = float(np.mean(ms))
+            ach = per_sample*store.total/(k_ms*1e-3)/1e9
+            leg[mode] = {'kernel': 'k_image' if mode == 'atomics' else 'k_image_bin + k_image_tiles',
+                         'kernel_ms': k_ms, 'samples_per_s': store.total/(k_ms*1e-3),
+                         'pixels_per_s': img.dims[0]*img.dims[1]/(k_ms*1e-3),
+                         'binned': ctx.counters()['samples_binned'],
+                         'roofline': {'bound': 'atomic requests' if mode == 'atomics' else 'hbm',
+                                      'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
+                                      'frac': ach/HBM_PEAK_GBS}}
+        ctx.image_mode('auto')
+        try:        # HBM bytes really moved by the two tile passes (PMC, profiles/traffic.json)
+            per = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+            key = 'image_tiles' if label == '512x512' else 'image_tiles_' + label
+            leg['tiles']['roofline']['traffic'] = per[key + '_bytes_per_sample']*leg['samples']
+            leg['tiles']['roofline']['traffic_from_profile'] = True
+            leg['tiles']['roofline']['traffic_source'] = per[key + '_source']
+        except (OSError, ValueError, KeyError):
+            leg['tiles']['roofline']['traffic'] = None
+        legs[label] = leg
     store.free()
-    try:        # HBM bytes really moved by the two tile passes (PMC, profiles/traffic.json)
-        per = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-        leg['tiles']['roofline']['traffic'] = per['image_tiles_bytes_per_sample']*leg['samples']
-        leg['tiles']['roofline']['traffic_source'] = per['image_tiles_source']
-    except (OSError, ValueError, KeyError):
-        leg['tiles']['roofline']['traffic'] = None
-    return leg
+    return legs
 
 
 def fail_line(args, world, reason):
@@ -284,7 +291,8 @@ def run_rank(args, cp, make_context, emit=print, hard_exit_after=None):
     socket.  Rank 0 then prints the ``"value": null`` line with the reason and every rank returns
     1.  ``hard_exit_after`` (seconds; main() sets it): a rank whose main thread still has not
     come back that long after a peer's failure was announced (it sits in a call that cannot be
-    interrupted, e.g. ncclCommInitRank) prints the line and leaves with os._exit(1)."""
+    interrupted, e.g. ncclCommInitRank) prints the line and leaves with os._exit(1); so does a
+    job of several ranks that has not finished after NXC_BENCH_DEADLINE_S (default 420 s)."""
     import traceback
     state = {'ctx': None, 'emitted': False, 'done': False}
 
@@ -313,6 +321,14 @@ def run_rank(args, cp, make_context, emit=print, hard_exit_after=None):
             timer.daemon = True
             timer.start()
 
+    limit = float(os.environ.get('NXC_BENCH_DEADLINE_S', '420' if cp.world > 1 else '0'))
+    if hard_exit_after is not None and limit > 0:
+        # last line of defence for a job of several ranks: whatever else fails to end it
+        import threading
+        watchdog = threading.Timer(limit, leave_now,
+                                   args=(f'the bench did not finish within {limit:.0f} s',))
+        watchdog.daemon = True
+        watchdog.start()
     try:
         rc = _run_rank(args, cp, make_context, emit_once, state, on_peer_failure)
         state['done'] = True
@@ -568,8 +584,14 @@ def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
                                       'value': ctr['particle_steps']/(float(np.mean(ms2))*1e-3),
                                       'unit': 'particle*steps/s'}
             # a-6..a-8 over stored samples: the reference's two-stage flow (Input.produce_image)
-            line['stored_samples_image'] = stored_samples_leg(ctx, inputs, img, aplanet, vrplanet,
-                                                              args.quantity)
+            with quiet():
+                img800 = ModelImage(inputs, dict(params, dims='800,800'), context=ctx)
+            legs = stored_samples_leg(ctx, inputs, {f'{args.dims}x{args.dims}': img,
+                                                    '800x800': img800}, aplanet, vrplanet,
+                                      args.quantity)
+            line['stored_samples_image'] = legs[f'{args.dims}x{args.dims}']
+            # the reference's default image size (ModelImage.py:53)
+            line['stored_samples_image_800'] = legs['800x800']
             # the adaptive-step driver (a-4), for the record: at the reference's chunk of 1e6
             # packets (Input.py:218) and at 1e7, which is what Input.run launches at once
             line['variable_step'] = variable_leg(ctx, inputs_var, 1_000_000)

@@ -1139,10 +1139,11 @@ int los_accumulate(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double
 }
 
 // Geometry of the tiled image: tile b = image rows ix = b (mod nb), nb a power of two; a tile's
-// pixels (ix / nb, iz) must fit the LDS tile.  False when the image has too many pixels for
-// NXC_TILE_MAX tiles (1024^2 and up): such images stay with k_image.
+// pixels (ix / nb, iz) must fit the LDS tile; the chunk shrinks as the tiles multiply
+// (nb x cap = NXC_TILE_STAGE, at most 256).  False when the image has too many pixels for
+// NXC_TILE_MAX tiles (above 1024^2): such images stay with k_image.
 struct TilePlan {
-    int nb_log2 = 0, tile_used = 0;
+    int nb_log2 = 0, tile_used = 0, cap = 256;
     size_t lds_bin = 0;
 };
 bool tile_plan(const nxc_handle *h, TilePlan *out)
@@ -1155,7 +1156,8 @@ bool tile_plan(const nxc_handle *h, TilePlan *out)
     if ((1 << lg) > NXC_TILE_MAX) return false;
     out->nb_log2 = lg;
     out->tile_used = ((nx + (1 << lg) - 1) >> lg) * nz;
-    out->lds_bin = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)(1 << lg) * NXC_TILE_CHUNK * 10 +
+    out->cap = std::min(256, NXC_TILE_STAGE >> lg);
+    out->lds_bin = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)(1 << lg) * out->cap * 10 +
                    (2 * (size_t)(1 << lg) + 3) * 4;
     return out->lds_bin <= 160 * 1024;
 }
@@ -1163,7 +1165,7 @@ bool tile_plan(const nxc_handle *h, TilePlan *out)
 // a-6..a-8 over samples on the device, through LDS-privatised tiles (nxc_kernels.hpp: k_image_bin,
 // k_image_tiles).  The samples go through in slabs so that the chunk scratch stays bounded
 // (10 bytes per sample of a slab at worst: every sample inside the image).
-template <typename T, bool DEFER>
+template <typename T, bool DEFER, int CAP>
 int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, const T *dy,
                     const T *dz, const T *dvy, const T *dfrac)
 {
@@ -1171,9 +1173,9 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
     // pass 2 forms the weights (DEFER): the image tables sit in front of its tile
     const size_t tables = DEFER ? (h->img_bytes + 15) & ~size_t(15) : 0;
     const size_t lds_tiles = tables + (size_t)NXC_TILE_PIXELS * 12;
-    if ((rc = prep_kernel(k_image_bin<T, DEFER>, tp.lds_bin))) return rc;
-    if ((rc = prep_kernel(k_image_tiles<DEFER>, lds_tiles))) return rc;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image_bin<T, DEFER>,
+    if ((rc = prep_kernel(k_image_bin<T, DEFER, CAP>, tp.lds_bin))) return rc;
+    if ((rc = prep_kernel(k_image_tiles<DEFER, CAP>, lds_tiles))) return rc;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_image_bin<T, DEFER, CAP>,
                                                         NXC_TILE_BIN_BLOCK, tp.lds_bin));
     const int nb = 1 << tp.nb_log2;
     const int64_t per_trip = (int64_t)NXC_TILE_BIN_BLOCK * nxc_tile_unroll<T>();
@@ -1187,13 +1189,13 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
         prod = (int64_t)h->n_cu * (per_cu > 0 ? per_cu : 1);
         prod = std::max<int64_t>(1, std::min<int64_t>(prod, (slab + per_trip - 1) / per_trip));
         span = ((slab + prod - 1) / prod + per_trip - 1) / per_trip * per_trip;
-        if (span > (int64_t(1) << 23)) {                  // a producer's chunk numbers are 16 bits
-            slab_max = (int64_t(1) << 23) * prod;
+        if (span > (int64_t(1) << 15) * CAP) {            // a producer's chunk numbers are 16 bits
+            slab_max = (int64_t(1) << 15) * CAP * prod;
             continue;
         }
-        mc = span / NXC_TILE_CHUNK + nb;
+        mc = span / CAP + nb;
         // scratch: payloads | pixels-in-tile | chunk lists [producer][tile][mc] | their lengths
-        const size_t entries = (size_t)prod * (size_t)mc * NXC_TILE_CHUNK;
+        const size_t entries = (size_t)prod * (size_t)mc * CAP;
         o_sl = entries * 8;
         o_list = o_sl + entries * 2;
         o_n = (o_list + (size_t)prod * nb * (size_t)mc * 2 + 255) & ~size_t(255);
@@ -1211,12 +1213,12 @@ int image_run_tiles(nxc_handle *h, const TilePlan &tp, int64_t p, const T *dx, c
     for (int64_t first = 0; first < p; first += slab) {
         const int64_t n = std::min<int64_t>(slab, p - first);
         const int64_t grid = (n + span - 1) / span;       // <= prod; the scratch regions keep their place
-        hipLaunchKernelGGL((k_image_bin<T, DEFER>), dim3((unsigned)grid), dim3(NXC_TILE_BIN_BLOCK),
+        hipLaunchKernelGGL((k_image_bin<T, DEFER, CAP>), dim3((unsigned)grid), dim3(NXC_TILE_BIN_BLOCK),
                            tp.lds_bin, h->stream, h->d_blob_img, (int64_t)h->img_bytes, n, span,
                            (int)mc, tp.nb_log2, dx + first, dy + first, dz + first, dvy + first,
                            dfrac + first, sw, sl, list, nlist, h->d_ctr);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_image_tiles<DEFER>, dim3((unsigned)(nb * ng)), dim3(NXC_IMAGE_BLOCK),
+        hipLaunchKernelGGL((k_image_tiles<DEFER, CAP>), dim3((unsigned)(nb * ng)), dim3(NXC_IMAGE_BLOCK),
                            lds_tiles, h->stream, h->d_blob_img, (int64_t)h->img_bytes, (int)grid,
                            (int)mc, tp.nb_log2, ng, tp.tile_used, (int)h->header.G.nz, sw, sl, list,
                            nlist, h->d_image, h->d_ctr);
@@ -1245,8 +1247,19 @@ int image_run(nxc_handle *h, int64_t p, const T *dx, const T *dy, const T *dz, c
         // image tables fit a CU's LDS next to a tile
         const bool f32_values = sizeof(T) == 4 || h->header.G.downcast_f32 != 0;
         const bool room = ((h->img_bytes + 15) & ~size_t(15)) + (size_t)NXC_TILE_PIXELS * 12 <= 160 * 1024;
-        if (f32_values && room) return image_run_tiles<T, true>(h, tp, p, dx, dy, dz, dvy, dfrac);
-        return image_run_tiles<T, false>(h, tp, p, dx, dy, dz, dvy, dfrac);
+        const bool defer = f32_values && room;
+#define NXC_TILES_CASE(C)                                                                       \
+        case C:                                                                                 \
+            return defer ? image_run_tiles<T, true, C>(h, tp, p, dx, dy, dz, dvy, dfrac)        \
+                         : image_run_tiles<T, false, C>(h, tp, p, dx, dy, dz, dvy, dfrac);
+        switch (tp.cap) {
+            NXC_TILES_CASE(256)
+            NXC_TILES_CASE(128)
+            NXC_TILES_CASE(64)
+        default:
+            return fail(NXC_ERR_STATE, "tile plan with an unknown chunk size");
+        }
+#undef NXC_TILES_CASE
     }
     if ((rc = prep_kernel(k_image<T>, h->img_bytes))) return rc;
     // as many 1024-thread groups as fit a CU (two for Na's 45 KB of tables), each staging the

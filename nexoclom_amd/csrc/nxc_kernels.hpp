@@ -750,11 +750,14 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 // ix = b (mod nb): every tile sees the same cut through the cloud, so the static assignment of
 // tiles to workgroups is balanced.  Packet counts are exact as before; the weight sums differ from
 // k_image's by the order of fp64 additions only (both are unordered).
-#ifndef NXC_TILE_CHUNK_N
-#define NXC_TILE_CHUNK_N 256
-#endif
-constexpr int NXC_TILE_CHUNK = NXC_TILE_CHUNK_N;     // entries per chunk
-constexpr int NXC_TILE_MAX = 32;            // tiles per image at most
+//
+// Image size.  Pass 1 keeps one staging block per tile in LDS, so the number of tiles fixes the
+// chunk: nb x CAP = 8192 staged entries (80 KB) whatever the image -- 32 tiles of 256-entry chunks
+// up to 512^2 pixels (262 144), 64 of 128 up to 524 288, 128 of 64 up to 1024^2 (the reference's
+// default 800 x 800, ModelImage.py:53, takes 128 tiles of 7 image rows).  A chunk of 64 still
+// leaves as 512 + 128 contiguous bytes.  Larger images stay with k_image.
+constexpr int NXC_TILE_STAGE = 8192;        // staged entries per workgroup of pass 1 (all tiles)
+constexpr int NXC_TILE_MAX = 128;           // tiles per image at most
 constexpr int NXC_TILE_PIXELS = 8192;       // pixels per tile at most (96 KB of LDS)
 #ifndef NXC_TILE_UNROLL_N
 #define NXC_TILE_UNROLL_N 4
@@ -808,7 +811,7 @@ NXC_DEV void image_add_pairs_n(bool has, int pix, double w, double cnt, double *
 #define NXC_TILE_BIN_BLOCK_N 1024
 #endif
 constexpr int NXC_TILE_BIN_BLOCK = NXC_TILE_BIN_BLOCK_N;
-template <typename T, bool DEFER>
+template <typename T, bool DEFER, int CAP>
 __global__ void __launch_bounds__(NXC_TILE_BIN_BLOCK)
 k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p, int64_t span,
             int mc, int nb_log2, const T *__restrict__ x, const T *__restrict__ y,
@@ -817,7 +820,7 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
             unsigned short *__restrict__ list, unsigned *__restrict__ nlist,
             DevCounters *__restrict__ ctr)
 {
-    constexpr int CAP = NXC_TILE_CHUNK, U = nxc_tile_unroll<T>();
+    constexpr int U = nxc_tile_unroll<T>();
     stage_tables(blob, stage_bytes);
     const ImageRegs IR = image_regs(lds_header().G);
     const int nb = 1 << nb_log2;
@@ -849,7 +852,7 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
         j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
         const size_t c = (chunk0 + j) * CAP;
 #pragma unroll
-        for (int t = 0; t < CAP / 64; t++) {
+        for (int t = 0; t < (CAP + 63) / 64; t++) {
             const int e = lane + 64 * t;
             if (e < n) { sw[c + e] = stw[b * CAP + e]; sl[c + e] = stl[b * CAP + e]; }
         }
@@ -945,7 +948,7 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
 // k = g (mod ng) into its LDS tile and hands the touched pixels to the resident image.  WEIGH: the
 // chunks hold {vy, masked frac} (k_image_bin<DEFER>) and the weight is formed here, so the image
 // tables are staged in front of the tile.
-template <bool WEIGH>
+template <bool WEIGH, int CAP>
 __global__ void __launch_bounds__(NXC_IMAGE_BLOCK)
 k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n_prod, int mc,
               int nb_log2, int ng, int tile_used, int nz,
@@ -953,7 +956,7 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
               const unsigned short *__restrict__ list, const unsigned *__restrict__ nlist,
               double *__restrict__ acc2, DevCounters *__restrict__ ctr)
 {
-    constexpr int CAP = NXC_TILE_CHUNK, E = CAP / 64, NF = 512 / CAP;
+    constexpr int E = (CAP + 63) / 64, NF = 512 / CAP;      // 512 entries in flight per wave
     int t0 = 0;
     ImageRegs IR = {};
     if (WEIGH) {

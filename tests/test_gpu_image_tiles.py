@@ -26,9 +26,14 @@ def _set(ctx, f, im, quantity):
 
 
 # (dims, tile_pixels, slab_samples): 32 row-interleaved tiles of a 512^2 image; a non-power-of-two
-# image in 4 tiles; the same in 32 tiles of 8 rows and five slabs; a single tile
+# image in 4 tiles; the same in 32 tiles of 8 rows and five slabs; a single tile; the reference's
+# DEFAULT image, 800 x 800 (ModelImage.py:53): 128 tiles of 7 rows, 64-entry chunks; 1024^2: 128
+# tiles of 8 rows, every pixel of every LDS tile in use; 640 x 700: 64 tiles, 128-entry chunks;
+# 800 x 800 in three slabs
 @pytest.mark.parametrize('dims,tile_pixels,slab', [((512, 512), 0, 0), ((200, 120), 0, 0),
-                                                   ((200, 120), 1024, 70001), ((64, 64), 0, 0)])
+                                                   ((200, 120), 1024, 70001), ((64, 64), 0, 0),
+                                                   ((800, 800), 0, 0), ((1024, 1024), 0, 0),
+                                                   ((640, 700), 0, 0), ((800, 800), 0, 100003)])
 @pytest.mark.parametrize('quantity', ['radiance', 'column'])
 @pytest.mark.parametrize('f32', [False, True])
 def test_tiled_image_equals_numpy_histogram_and_the_atomic_path(tiles, dims, tile_pixels, slab,
@@ -120,10 +125,35 @@ def test_tiled_image_against_the_reference_histogram_vectors(tiles):
     assert np.array_equal(cnt.astype(float), ref)
 
 
+@pytest.mark.parametrize('dims', [(800, 800), (1024, 1024)])
+def test_large_tiled_image_counts_equal_numpy_histogram2d(tiles, dims):
+    """np.histogram2d itself (math/histogram.py:34) at the reference's default image size and at
+    1024^2, on 2e6 float32 samples with every edge value among them: exact counts."""
+    ctx = tiles
+    rng = np.random.default_rng(11)
+    p = 2_000_000
+    edges_x, edges_z = np.linspace(-4, 4, dims[0] + 1), np.linspace(-4, 4, dims[1] + 1)
+    px = rng.normal(0, 1.7, p).astype(np.float32)
+    pz = rng.normal(0, 1.7, p).astype(np.float32)
+    px[:dims[0] + 1] = edges_x.astype(np.float32)
+    pz[dims[0] + 1:dims[0] + dims[1] + 2] = edges_z.astype(np.float32)
+    w = rng.uniform(0.1, 1, p).astype(np.float32)
+    ctx.set_image(np.eye(3), 0.0, 1.0, 'column', edges_x, edges_z, [])
+    ctx.image_mode('tiles')
+    ctx.image_accumulate(px, -np.ones_like(px), pz, np.zeros_like(px), w)
+    img, cnt = ctx.image_download()
+    x64, z64 = px.astype(np.float64), pz.astype(np.float64)
+    ref, _, _ = np.histogram2d(x64, z64, bins=list(dims), range=[[-4, 4], [-4, 4]])
+    refw, _, _ = np.histogram2d(x64, z64, bins=list(dims), range=[[-4, 4], [-4, 4]],
+                                weights=w.astype(np.float64))
+    assert np.array_equal(cnt.astype(float), ref) and ref.sum() > 1.8e6
+    np.testing.assert_allclose(img, refw, rtol=1e-12, atol=0)
+
+
 def test_tiled_image_refuses_what_it_cannot_hold(tiles):
     ctx = tiles
     f = H.mercury_forces('Na', 1.3)
-    im = H.image_setup(f, 'column', dims=(1024, 1024))
+    im = H.image_setup(f, 'column', dims=(1032, 1024))       # one row beyond 128 tiles of 8
     _set(ctx, f, im, 'column')
     ctx.image_mode('tiles')
     from nexoclom_amd.hip_api import HipError

@@ -276,8 +276,10 @@ def test_rccl_single_rank_allreduce(ctx, coracle):
 def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
     """nxc_comm_set_timeout: a wait on a collective is bounded.  The hang is injected
     (nxc_comm_test_stall holds the stream as a lost peer would); the waiting call must come back
-    with NXC_ERR_RCCL near the deadline, the communicator must be gone (ncclCommAbort), and the
-    handle must stay usable once the stream has drained."""
+    with NXC_ERR_RCCL once the deadline has passed, the communicator must be gone (ncclCommAbort),
+    and the handle must stay usable once the stream has drained.  (ncclCommAbort waits for the
+    device: an RCCL kernel leaves as soon as it sees the abort flag, the injected stall only when
+    its time is up -- so here the call returns when the stall ends, not at 0.4 s.)"""
     import time
     from nexoclom_amd import hip_api
     f = H.mercury_forces('Na', 1.3)
@@ -296,7 +298,7 @@ def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
     with pytest.raises(hip_api.HipError, match='did not complete within 0.4 s') as err:
         ctx.synchronize()
     waited = time.perf_counter() - t0
-    assert err.value.code == hip_api.NXC_ERR_RCCL and 0.35 < waited < 1.5
+    assert err.value.code == hip_api.NXC_ERR_RCCL and 0.35 < waited < 3.0
     with pytest.raises(hip_api.HipError, match='nxc_comm_init'):      # no communicator any more
         ctx.image_allreduce()
     ctx.synchronize()                                                  # the stall ends by itself
@@ -310,7 +312,7 @@ def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
     t0 = time.perf_counter()
     with pytest.raises(hip_api.HipError, match='peer rank reported a failure') as err:
         ctx.synchronize()
-    assert err.value.code == hip_api.NXC_ERR_RCCL and time.perf_counter() - t0 < 1.0
+    assert err.value.code == hip_api.NXC_ERR_RCCL and time.perf_counter() - t0 < 3.0
     ctx.synchronize()
     # the handle works on: a fresh communicator, a collective, a pass
     ctx.comm_init(ctx.comm_unique_id(), 0, 1)
