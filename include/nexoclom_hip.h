@@ -59,8 +59,10 @@ typedef enum {
     NXC_ERR_NO_DEVICE = -3,  /* no gfx950-class device visible                          */
     NXC_ERR_RCCL = -4,       /* librccl missing or a collective failed                  */
     NXC_ERR_STATE = -5,      /* handle not in the state the call needs                  */
-    NXC_ERR_NOMEM = -6       /* device memory: an allocation failed or the result would
+    NXC_ERR_NOMEM = -6,      /* device memory: an allocation failed or the result would
                                 not fit (callers may split the work and call again)     */
+    NXC_ERR_INCOMPLETE = -7  /* nxc_synchronize after nxc_integrate_const_streamed: the
+                                kernel gave up waiting for its queue; results are partial */
 } nxc_status;
 
 /* Scalars and table consumed by state() (what Output.__init__ hangs on `output`,
@@ -338,7 +340,13 @@ int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double
  * (soa0 must stay valid until nxc_synchronize); afterwards the packets are the resident set, the
  * image holds their samples and nxc_counters_get reports the pass.  Same results as
  * nxc_packets_upload + nxc_integrate_const_async (the order of the queue changes no packet).
- * Not with moons or surface re-emission set (NXC_ERR_STATE: upload first). */
+ * Not with moons or surface re-emission set (NXC_ERR_STATE: upload first).
+ * The persistent kernel waits for its pieces while small ordering kernels on a second stream
+ * prepare them; where those cannot run beside it (a profiler in counter mode serialises kernels)
+ * a wave gives up after three seconds of waiting, the launch ends with part of the packets
+ * integrated (nxc_counters.unfinished counts the rest), and the nxc_synchronize that follows
+ * returns NXC_ERR_INCOMPLETE: the image and counters are partial, the resident set is dropped, the
+ * handle stays usable (nxc_packets_upload + nxc_integrate_const_async is the sequential form). */
 int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, int32_t pieces,
                                  double step, int64_t n_iter, double outeredge, uint32_t flags);
 

@@ -567,7 +567,12 @@ class Output:
         """Apply the reference's on-disk transformations (compress filter, 32-bit down-cast,
         Output.py:522-543), register in the inputs' catalogue, optionally write an .npz.  Rows
         that came from the compact-rows kernels are already filtered (on the 64-bit frac, like
-        the reference: a float32 underflow of frac must not drop a row) and narrowed."""
+        the reference: a float32 underflow of frac must not drop a row) and narrowed -- when the
+        Output was made to be saved.  One made with save=False keeps 64-bit rows in HBM; saving it
+        after all brings them to the host and narrows them there, so that what is catalogued (and
+        what ModelImage / LOSResult bin) is float32 / int32 as Output.py:528-543 has it."""
+        if self._store is not None and self._X is None and not self._store.narrow:
+            self._spill()
         if self._store is None or self._X is not None:
             if self._store is None and self.compress and len(self.X) > 0 and 'frac' in self.X:
                 keep = self.X.frac.values > 0

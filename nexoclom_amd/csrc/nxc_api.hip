@@ -387,6 +387,7 @@ struct nxc_handle {
 
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
+    bool streamed_pending = false;   // nxc_integrate_const_streamed since the last nxc_synchronize
     bool coll_pending = false;       // a collective sits on `stream` and nobody has waited for it yet
     std::atomic<bool> abort_requested{false};   // nxc_comm_request_abort (any thread)
     double coll_timeout_s = 120.0;   // nxc_comm_set_timeout / NXC_COLLECTIVE_TIMEOUT_S
@@ -1422,6 +1423,25 @@ int nxc_synchronize(nxc_handle *h)
     if (!h) return fail(NXC_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(stream_sync(h));
+    if (h->streamed_pending) {
+        // the pipelined pass is the one launch whose kernel may give up by itself (a wave that has
+        // waited three seconds for the next piece of its queue): say so instead of handing over a
+        // partial image as if it were the result
+        h->streamed_pending = false;
+        DevCounters c;
+        HIPCHK(hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+        if (c.unfinished != 0) {
+            h->n_packets = 0;                  // the queue holds a partly ordered set: upload again
+            char buf[256];
+            std::snprintf(buf, sizeof buf,
+                          "the pipelined pass gave up waiting for its queue (%llu packets not "
+                          "integrated): the ordering kernels did not run beside the persistent "
+                          "kernel (a profiler serialising kernels?); image and counters are partial "
+                          "-- upload with nxc_packets_upload and run nxc_integrate_const_async",
+                          (unsigned long long)c.unfinished);
+            return fail(NXC_ERR_INCOMPLETE, buf);
+        }
+    }
     return NXC_OK;
 }
 
@@ -2082,9 +2102,12 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         first = std::min(first, n / pieces);
         for (int p = 1; p < pieces; p++) bound[(size_t)p] = first + (n - first) * (p - 1) / (pieces - 1);
     }
+    // fault injection for the tests of the give-up path: the last piece is never published
+    const bool withhold = std::getenv("NXC_TEST_WITHHOLD_LAST_PIECE") != nullptr;
     for (int p = 0; p < pieces; p++) {
         const int64_t p0 = bound[(size_t)p], len = bound[(size_t)p + 1] - p0;
         if (len <= 0) continue;
+        if (withhold && p == pieces - 1 && pieces > 1) break;
         hipError_t e = hipSuccess;
         for (int c = 0; c < 8 && e == hipSuccess; c++)
             e = hipMemcpyAsync(h->d_packets + c * n + p0, soa0 + c * n + p0, (size_t)len * 8,
@@ -2105,6 +2128,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         if (hipGetLastError() != hipSuccess) return give_up(fail(NXC_ERR_HIP, "streamed upload: launch failed"));
     }
     h->have_order = true;            // pieces sorted one by one: still a valid queue order
+    h->streamed_pending = true;
     // the handle's stream continues after the ordering stream as well
     HIPCHK(hipEventRecord(h->ev_piece[32], h->stream2));
     HIPCHK(hipStreamWaitEvent(h->stream, h->ev_piece[32], 0));

@@ -39,8 +39,8 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
 ABI_VERSION = 2
 
 
-NXC_ERR_HIP, NXC_ERR_ARG, NXC_ERR_NO_DEVICE, NXC_ERR_RCCL, NXC_ERR_STATE, NXC_ERR_NOMEM = \
-    -1, -2, -3, -4, -5, -6
+NXC_ERR_HIP, NXC_ERR_ARG, NXC_ERR_NO_DEVICE, NXC_ERR_RCCL, NXC_ERR_STATE, NXC_ERR_NOMEM, \
+    NXC_ERR_INCOMPLETE = -1, -2, -3, -4, -5, -6, -7
 
 
 class HipError(RuntimeError):
@@ -269,7 +269,12 @@ class Context:
         return buf.value.decode()
 
     def synchronize(self):
-        self._check(self.lib.nxc_synchronize(self._h))
+        try:
+            self._check(self.lib.nxc_synchronize(self._h))
+        except HipError as exc:
+            if exc.code == NXC_ERR_INCOMPLETE:
+                self.n_packets = 0
+            raise
 
     def mem_info(self):
         """(free, total) bytes of device memory."""
@@ -506,7 +511,8 @@ class Context:
     def integrate_const_streamed(self, soa, step, n_iter, outeredge, image=True, pieces=16):
         """Upload the (8, N) host array and integrate it in one pipelined pass (the next piece
         crosses PCIe while the current one is integrated).  Asynchronous: ``synchronize()`` before
-        touching ``soa`` or reading results."""
+        touching ``soa`` or reading results -- it raises HipError (code NXC_ERR_INCOMPLETE) when
+        the kernel gave up waiting for its queue, in which case nothing of the pass is valid."""
         soa = _f64(soa)
         assert soa.ndim == 2 and soa.shape[0] == 8
         self._keep = soa                      # the copies read it until the stream is drained

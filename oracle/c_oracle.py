@@ -38,7 +38,8 @@ class _Bodies(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, '_build', 'liboracle.so')
-    if force or not os.path.exists(so):
+    if force or not all(os.path.exists(os.path.join(_HERE, '_build', n)) for n in
+                        ('liboracle.so', 'liboracle_libm.so', 'liboracle_2r.so')):
         subprocess.check_call(['make', '-C', _HERE, '-s'])
     return so
 
@@ -52,9 +53,11 @@ def _f64(a):
 
 
 class COracle:
-    def __init__(self, libm=False):
+    def __init__(self, libm=False, two_roundings=False):
+        """two_roundings: the build whose tableau terms round twice, like NumPy's (the default
+        build fuses them, like the kernels)."""
         build()
-        name = 'liboracle_libm.so' if libm else 'liboracle.so'
+        name = 'liboracle_libm.so' if libm else 'liboracle_2r.so' if two_roundings else 'liboracle.so'
         self.lib = C.CDLL(os.path.join(_HERE, '_build', name))
         self.lib.ora_integrate_const.restype = C.c_int64
         self.lib.ora_integrate_const_bodies.restype = C.c_int64

@@ -24,6 +24,12 @@ Vectors
   g4_var.npz        variable driver around the reference rk5, 128 packets
   g5_hist.npz       Histogram2d edge cases at 512x512 (on-edge, right edge, outside)
   g6_rotation.npz   rotation_matrix / image_rotation for several sub-observer points
+  g8_const20k.npz   the bench workload at BASELINE's image geometry, around the reference's rk5:
+                    20 000 packets (X0 = tests.helpers.sample_x0(20000, 8008, 50000.), not
+                    stored) x all 1667 steps: per-packet step counts, alive count and sum(frac)
+                    per step, the 512 x 512 packet-count image of the float32 samples (sparse),
+                    and of the radiance / column images their row sums, column sums and every
+                    16th pixel -- what the -m gpu suite holds the fused-tableau kernels to
 """
 import os
 import sys
@@ -119,6 +125,44 @@ def main():
                     tag = f'{name}_{q}_{"f32" if dc else "f64"}'
                     g3[tag + '_image'], g3[tag + '_counts'] = img_o, cnt_o
     np.savez_compressed(os.path.join(OUT, 'g3_const.npz'), **g3)
+
+    # ---- G8: the bench workload, 20 000 packets, 512 x 512, around the imported rk5 -------------
+    f = H.mercury_forces('Na', 1.3)
+    n8, seed8, endtime8, step8, edge8 = 20000, 8008, 50000., 30., 25.
+    X0 = H.sample_x0(n8, seed8, endtime8)
+    out = ref_loader.duck_output(f, step8)
+    res_ref, _, work_ref = O.constant_step_driver(
+        f, X0, endtime8, step8, edge8, rk5_fn=lambda X, h: rk5m.rk5(out, X, h))
+    res_o, _, work_o = O.constant_step_driver(f, X0, endtime8, step8, edge8)
+    assert work_ref == work_o and np.array_equal(res_ref, res_o), 'oracle driver != reference (g8)'
+    del res_o
+    n_iter8 = res_ref.shape[2] - 1
+    g8 = dict(params=np.array([n8, seed8, endtime8, step8, edge8]), work=np.int64(work_ref),
+              steps=(res_ref[:, 7, :n_iter8] > 0).sum(axis=1).astype(np.uint16),
+              alive_per_step=(res_ref[:, 7, :] > 0).sum(axis=0).astype(np.int32),
+              fracsum_per_step=res_ref[:, 7, :].sum(axis=0))
+    s8 = O.samples_from_results(res_ref, compress=True, downcast=True)
+    del res_ref
+    for q in ('radiance', 'column'):
+        im = H.image_setup(f, q, dims=(512, 512))
+        img, cnt, _, _ = O.create_image(s8['x'], s8['y'], s8['z'], s8['vy'], s8['frac'],
+                                        f.vrplanet, im['M'], q, im['g_tables'], im['dims'],
+                                        im['xrange'], im['zrange'], im['apix'])
+        pts = np.stack([s8['x'], s8['y'], s8['z']], 1)
+        pobs = np.array(np.matmul(im['M'], pts.T).T)
+        hh = histm.Histogram2d(pobs[:, 0], pobs[:, 2], bins=im['dims'],
+                               range=[list(im['xrange']), list(im['zrange'])])
+        assert np.array_equal(hh.histogram, cnt), 'oracle binning != reference Histogram2d (g8)'
+        if 'count_pix' in g8:
+            assert np.array_equal(cnt.ravel()[g8['count_pix']], g8['count_val']) and \
+                cnt.sum() == g8['count_val'].sum(), 'radiance and column count images differ'
+        else:
+            nz = np.flatnonzero(cnt.ravel())
+            g8['count_pix'], g8['count_val'] = nz.astype(np.uint32), cnt.ravel()[nz].astype(np.uint16)
+            assert cnt.max() < 65536
+        g8[q + '_rowsum'], g8[q + '_colsum'] = img.sum(axis=1), img.sum(axis=0)
+        g8[q + '_every16'] = img.ravel()[::16].copy()
+    np.savez_compressed(os.path.join(OUT, 'g8_const20k.npz'), **g8)
 
     # ---- G4 variable driver -------------------------------------------------------------------
     f = H.mercury_forces('Na', 1.3)

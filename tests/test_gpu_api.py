@@ -87,6 +87,31 @@ def test_save_applies_compress_and_float32(ctx):
     assert back.X.x.dtype == np.float64 and back.X.Index.dtype == np.int64
 
 
+def test_saving_an_output_made_without_save_still_stores_float32(ctx):
+    """Output(..., save=False) keeps 64-bit rows in HBM; a later out.save() must catalogue what
+    the reference's save() would (float32 / int32, Output.py:528-543), so that the image of the
+    catalogue equals the one of an Output saved at construction -- packet counts exactly."""
+    params = {'quantity': 'radiance', 'dims': '128,128'}
+    images = []
+    for save in (True, False):
+        inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
+        inputs.options.endtime = type(inputs.options.endtime)(9000., 's')
+        out = Output(inputs, 4000, compress=True, seed=11, context=ctx, save=save)
+        if not save:
+            assert len(inputs._catalogue) == 0
+            store = out.resident_rows(ctx)
+            assert store is not None and not store[0].narrow
+            out.save()
+        assert len(inputs._catalogue) == 1
+        assert out.X.x.dtype == np.float32 and out.X.frac.dtype == np.float32
+        assert out.X.Index.dtype == np.int32 and out.X0.x.dtype == np.float32
+        images.append((inputs.produce_image(params, context=ctx), out.X))
+    (a, xa), (b, xb) = images
+    assert a.packet_image.sum() > 1e4 and np.array_equal(a.packet_image, b.packet_image)
+    np.testing.assert_allclose(a.image, b.image, rtol=1e-12, atol=0)
+    assert len(xa) == len(xb) and all(np.array_equal(xa[c].values, xb[c].values) for c in xa)
+
+
 @pytest.mark.parametrize('quantity', ['radiance', 'column'])
 def test_modelimage_two_stage_equals_streaming_equals_oracle(ctx, quantity):
     """inputs.run() + produce_image() (the reference's data flow through stored float32 packets)

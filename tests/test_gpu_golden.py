@@ -113,6 +113,62 @@ def test_fused_image_against_the_reference_vectors(ctx, quantity, downcast):
     np.testing.assert_allclose(image2, g[tag + '_image'], rtol=1e-9, atol=0)
 
 
+@pytest.mark.parametrize('quantity', ['radiance', 'column'])
+def test_bench_workload_against_g8_from_the_reference_rk5(ctx, quantity):
+    """g8_const20k.npz: 20 000 packets of the bench workload through the reference's OWN rk5.py /
+    state.py / Histogram2d (oracle/make_golden.py), BASELINE's 512 x 512 image of the float32
+    samples.  The kernels fuse the tableau terms (one rounding where NumPy has two), so this --
+    not the bit-exact comparison with the C checker -- is what ties their counts to the
+    reference: every packet's step count and every pixel's packet count exactly, through the
+    fused pass AND through stored rows -> LDS tiles; brightness to 1e-9 (north_star: 1e-6)."""
+    g = load('g8_const20k.npz')
+    n, seed, endtime, step, edge = g['params']
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None); ctx.set_bodies(None)
+    X0 = H.sample_x0(int(n), int(seed), endtime)
+    nsteps, n_iter = n_output_steps(endtime, step)
+    im = H.image_setup(f, quantity, dims=(512, 512))
+    ref_cnt = np.zeros(512*512, dtype=np.uint64)
+    ref_cnt[g['count_pix']] = g['count_val']
+
+    def check(image, counts):
+        assert np.array_equal(counts.ravel(), ref_cnt)
+        np.testing.assert_allclose(image.sum(axis=1), g[quantity + '_rowsum'], rtol=1e-9)
+        np.testing.assert_allclose(image.sum(axis=0), g[quantity + '_colsum'], rtol=1e-9)
+        np.testing.assert_allclose(image.ravel()[::16], g[quantity + '_every16'], rtol=1e-9)
+    # the fused pass
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], quantity, im['xedges'], im['zedges'],
+                  im['g_tables'], downcast_f32=True)
+    ctx.upload_packets(X0)
+    res = ctx.integrate_const(step, n_iter, edge, image=True, want_steps=True)
+    assert ctx.counters()['particle_steps'] == int(g['work'])
+    assert np.array_equal(res['steps'], g['steps'].astype(res['steps'].dtype))
+    check(*ctx.image_download())
+    # stored float32 rows (what save() keeps) -> k_image_bin + k_image_tiles, and -> k_image
+    ctx.upload_packets(X0)
+    store = ctx.integrate_const_rows(step, n_iter, edge, narrow=True, resident=True)['store']
+    alive = g['alive_per_step']
+    assert store.total == int(alive.sum())
+    try:
+        for mode in ('tiles', 'atomics'):
+            ctx.set_image(im['M'], f.vrplanet, im['apix'], quantity, im['xedges'], im['zedges'],
+                          im['g_tables'], downcast_f32=False)
+            ctx.image_mode(mode)
+            ctx.image_accumulate_rows(store)
+            check(*ctx.image_download())
+        # the stored rows themselves: records alive and sum(frac) per step (float32 values)
+        rows, _ = store.download()
+        k = np.rint((endtime - rows[0].astype(np.float64))/step).astype(np.int64)
+        assert np.array_equal(np.bincount(k, minlength=nsteps), alive)
+        np.testing.assert_allclose(np.bincount(k, weights=rows[7].astype(np.float64),
+                                               minlength=nsteps),
+                                   g['fracsum_per_step'], rtol=1e-6)
+    finally:
+        ctx.image_mode('auto')
+        store.free()
+
+
 def test_variable_driver_against_the_reference_vectors(ctx):
     g = load('g4_var.npz')
     f = H.mercury_forces('Na', 1.3)

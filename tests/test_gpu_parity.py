@@ -495,6 +495,48 @@ def test_streamed_pass_equals_upload_then_integrate(ctx):
         assert np.array_equal(ctx.image_download()[1], want_counts)
 
 
+def test_a_streamed_pass_that_gives_up_is_reported_and_the_handle_lives_on(ctx, monkeypatch):
+    """The pipelined pass is the one launch whose kernel may end by itself before its work is
+    done: a wave that has waited three seconds for the next piece of the queue leaves.  Forced
+    here by never publishing the last piece (NXC_TEST_WITHHOLD_LAST_PIECE): the synchronize that
+    follows must raise NXC_ERR_INCOMPLETE -- not hand over the partial image -- and the handle
+    must work on: upload + plain pass give the full result."""
+    from nexoclom_amd import hip_api
+    f = H.mercury_forces('Na', 1.3)
+    nsteps, n_iter = O.n_output_steps(20000., 30.)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None); ctx.set_bodies(None)
+    im = H.image_setup(f, 'radiance', dims=(64, 64))
+    ctx.set_image(im['M'], f.vrplanet, im['apix'], 'radiance', im['xedges'], im['zedges'],
+                  im['g_tables'], downcast_f32=True)
+    soa = np.ascontiguousarray(H.sample_x0(60000, 12, 20000.).T)
+    ctx.upload_soa(soa)
+    ctx.integrate_const(30., n_iter, 25., image=True)
+    want_ctr, (want, want_counts) = ctx.counters(), ctx.image_download()
+    ctx.image_clear()
+    monkeypatch.setenv('NXC_TEST_WITHHOLD_LAST_PIECE', '1')
+    ctx.integrate_const_streamed(soa, 30., n_iter, 25., image=True, pieces=4)
+    monkeypatch.delenv('NXC_TEST_WITHHOLD_LAST_PIECE')
+    with pytest.raises(hip_api.HipError, match='gave up waiting for its queue') as err:
+        ctx.synchronize()
+    assert err.value.code == hip_api.NXC_ERR_INCOMPLETE
+    part = ctx.counters()
+    assert part['unfinished'] > 0 and 0 < part['particle_steps'] < want_ctr['particle_steps']
+    assert ctx.n_packets == 0
+    with pytest.raises(hip_api.HipError, match='no resident packets'):
+        ctx.integrate_const(30., n_iter, 25., image=True)
+    ctx.synchronize()                                            # the error is reported once
+    # the sequential form, and then the pipelined pass again, unharmed
+    ctx.image_clear()
+    ctx.upload_soa(soa)
+    ctx.integrate_const(30., n_iter, 25., image=True)
+    assert ctx.counters() == want_ctr and np.array_equal(ctx.image_download()[1], want_counts)
+    ctx.image_clear()
+    ctx.integrate_const_streamed(soa, 30., n_iter, 25., image=True, pieces=4)
+    ctx.synchronize()
+    assert ctx.counters() == want_ctr and np.array_equal(ctx.image_download()[1], want_counts)
+
+
 def test_rows_of_runs_without_live_records_and_of_a_single_packet(ctx):
     """Edge cases of the rows protocol: packets that all start dead (no row at all: an empty store
     that can still be downloaded, binned and freed), and a single packet (one lane of one wave;

@@ -103,3 +103,95 @@ def test_c_oracle_against_the_reference_arithmetic_at_3000_packets(coracle, quan
     assert np.array_equal(c['counts'], ref_cnt.astype(np.uint64))        # bit-exact packet counts
     np.testing.assert_allclose(c['image'], ref_img, rtol=1e-6, atol=0)   # north_star
     np.testing.assert_allclose(c['image'], ref_img, rtol=1e-9, atol=0)   # what we get
+
+
+def _g8():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g8_const20k.npz'),
+                   allow_pickle=False)
+
+
+@pytest.mark.parametrize('quantity', ['radiance', 'column'])
+def test_c_oracle_against_g8_the_reference_rk5_at_20000_packets(coracle, quantity):
+    """g8_const20k.npz was produced by the reference's OWN rk5.py / state.py / Histogram2d (loaded
+    by path, oracle/make_golden.py) on 20 000 packets of the bench workload with BASELINE's 512 x
+    512 image.  The C checker -- the kernels' arithmetic, tableau terms fused -- must reproduce
+    every step count and every pixel's packet count; brightness to 1e-9 (north_star: 1e-6)."""
+    from oracle import np_oracle as O
+    from tests import helpers as H
+    g = _g8()
+    n, seed, endtime, step, edge = g['params']
+    f = H.mercury_forces('Na', 1.3)
+    X0 = H.sample_x0(int(n), int(seed), endtime)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    im = H.image_setup(f, quantity, dims=(512, 512))
+    desc = coracle.image_desc(im['M'], f.vrplanet, im['apix'], quantity, im['g_tables'],
+                              im['xedges'], im['zedges'], downcast=True)
+    c = coracle.integrate_const(f, X0, step, n_iter, edge, img=desc, threads=coracle.max_threads())
+    assert c['work'] == int(g['work'])
+    assert np.array_equal(c['steps'], g['steps'].astype(np.int64))
+    ref_cnt = np.zeros(512*512, dtype=np.uint64)
+    ref_cnt[g['count_pix']] = g['count_val']
+    assert ref_cnt.sum() > 1.2e6
+    assert np.array_equal(c['counts'].ravel(), ref_cnt)
+    np.testing.assert_allclose(c['image'].sum(axis=1), g[quantity + '_rowsum'], rtol=1e-9)
+    np.testing.assert_allclose(c['image'].sum(axis=0), g[quantity + '_colsum'], rtol=1e-9)
+    np.testing.assert_allclose(c['image'].ravel()[::16], g[quantity + '_every16'], rtol=1e-9)
+
+
+def test_two_roundings_build_is_the_numpy_arithmetic_to_1e14():
+    """-DORACLE_TABLEAU_TWO_ROUNDINGS (with -DNXC_TABLEAU_TWO_ROUNDINGS in the kernels) restores
+    NumPy's two roundings per tableau term (rk5.py:33-35,41-43).  That build must stay alive and
+    stay closer to the reference than the fused one: one step agrees with the NumPy oracle to 1e-14
+    (what is left are the 1-ulp pow / exp / log), the fused build to 1e-13; a whole run keeps
+    every step count and lands closer to the NumPy trajectory than the fused build does."""
+    from oracle import np_oracle as O
+    from tests import helpers as H
+    two, fused = COracle(two_roundings=True), COracle()
+    f = H.mercury_forces('Na', 1.3)
+    X = H.random_cloud(4096, 9)
+    h = np.random.default_rng(3).uniform(1, 120, len(X))
+    ref, dref = O.rk5(f, X, h, want_delta=True)
+    a, da = two.rk5(f, X, h, want_delta=True)
+    b, _ = fused.rk5(f, X, h, want_delta=True)
+    scale = np.maximum(np.abs(ref), 1e-3)
+    assert (np.abs(a - ref)/scale).max() < 1e-14
+    assert (np.abs(b - ref)/scale).max() < 1e-13
+    assert not np.array_equal(a, b)                      # the switch does switch something
+    np.testing.assert_allclose(da, dref, rtol=1e-9, atol=1e-22)
+    n, endtime, step, edge = 1500, 50000., 30., 25.
+    X0 = H.sample_x0(n, 5150, endtime)
+    nsteps, n_iter = O.n_output_steps(endtime, step)
+    results, _, work = O.constant_step_driver(f, X0, endtime, step, edge)
+    last = (results[:, 7, :n_iter] > 0).sum(axis=1)
+    fin = results[np.arange(n), :, last]
+    err = {}
+    for name, co in (('two', two), ('fused', fused)):
+        c = co.integrate_const(f, X0, step, n_iter, edge, threads=co.max_threads())
+        assert c['work'] == work and np.array_equal(c['steps'], last), name
+        err[name] = np.nanmax(np.abs(c['final'] - fin)/np.maximum(np.abs(fin), 1e-3))
+    assert err['two'] < 1e-9 and err['fused'] < 1e-9
+
+
+def test_variable_driver_step_counts_against_the_numpy_arithmetic(coracle):
+    """The adaptive driver decides accept / reject on delta, which the fused tableau terms also
+    touch (Output.py:281-342): attempts per packet and final step sizes of the C checker against
+    the NumPy oracle (the reference's arithmetic) on 1500 packets.  A decision that lands within
+    rounding of its threshold may flip, so equality is not asserted, only counted: at most 1 packet
+    in 500 may differ in its attempt count, and every state agrees to 1e-6 (north_star) -- in
+    practice none differs."""
+    from oracle import np_oracle as O
+    from tests import helpers as H
+    f = H.mercury_forces('Na', 1.3)
+    n = 1500
+    X0 = H.sample_x0(n, 616, 20000.)
+    X0[:, 0] = np.random.default_rng(61).random(n)*20000.
+    fin, hs, work = O.variable_step_driver(f, X0, 1e-4, 25.0)
+    for co in (coracle, COracle(two_roundings=True)):
+        cfin, chs, cwork, bad = co.integrate_var(f, X0, 1e-4, 25.0)
+        assert bad == 0
+        assert abs(cwork - work) <= max(2, work//100000)
+        differ = int((chs != hs).sum())
+        close = np.isclose(chs, hs, rtol=1e-6, atol=0)
+        assert (~close).sum() <= n//500, (differ, int((~close).sum()))
+        np.testing.assert_allclose(cfin[close], fin[close], rtol=1e-6, atol=1e-9)
