@@ -48,6 +48,7 @@ if ROOT not in sys.path:
 
 ALGO_BYTES_PER_PARTICLE_STEP = 128      # 8 fp64 read + 8 fp64 written
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GUIDE_COPY_GBS = 6290.0                 # same guide: float4 copy, measured
 SEED = 1234
 INFILE = os.path.join(ROOT, 'nexoclom_amd', 'inputfiles', 'Na.mercury.bench.input')
 
@@ -144,17 +145,21 @@ def cpu_baseline(args, inputs, variable=False):
                              f'in {t_c:.1f} s'}
 
 
-def profile_ceilings(k_ms, particle_steps, clock_mhz):
+def profile_ceilings(k_ms, particle_steps, clock_mhz, wave_trips=None, binned=None):
     """HBM traffic and the ceilings that bind the fused kernel.
 
-    From the committed PMC profile (profiles/traffic.json): HBM bytes, VALU wave-instructions and
-    memory-side atomic requests per launch, scaled to this run's particle*steps, and the share of
-    the kernel's cycles in which a VALU instruction was issuing (``valu_busy_frac_pmc``:
-    SQ_ACTIVE_INST_VALU x 4 / SIMD-cycles, which charges a 32-bit instruction a full slot).
-    ``valu_issue_floor_ms`` is the cost model of DESIGN.md section 3 instead -- per wave trip
-    512 fp64 instructions at one 4-cycle issue slot, 13 v_rcp/v_rsq_f64 at 3.3 slots, 284 32-bit
-    instructions at half a slot (profiles/cost_model.json holds the figures used) -- at the clock THIS run held
-    (``clock_mhz``: in-kernel stamps of a diagnostic launch, or the profile's if not measured)."""
+    Counted in THIS run where the kernel can count it itself: ``wave_trips`` (trips of a wave
+    through the persistent step loop, nxc_counters.wave_trips) times the static VALU mix of one
+    trip (profiles/cost_model.json, from tools/isa_census.py) gives the VALU wave-instructions;
+    the binned samples are the memory-side atomic requests (one pair-atomic instruction per binned
+    sample, image_add_pairs); ``lanes_active`` = particle_steps / (64 x wave_trips).  A regression
+    in lane occupancy, refill behaviour or sample counts therefore shows in the driver's line.
+    Only ``traffic`` (HBM bytes: FETCH_SIZE / WRITE_SIZE need the PMC counters) and
+    ``valu_busy_frac_pmc`` come from the committed profile (profiles/traffic.json), scaled to
+    this run's particle*steps and marked ``from_profile``.
+    ``valu_issue_floor_ms``: per wave trip the cost model's fp64 instructions at one 4-cycle issue
+    slot, v_rcp/v_rsq_f64 at 3.3 slots, 32-bit instructions at half a slot, at the clock THIS run
+    held (``clock_mhz``: in-kernel stamps of a diagnostic launch, or the profile's)."""
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     cfile = os.path.join(ROOT, 'profiles', 'cost_model.json')
     try:
@@ -164,27 +169,43 @@ def profile_ceilings(k_ms, particle_steps, clock_mhz):
         return None, None
     scale = particle_steps/float(prof.get('particle_steps_per_launch', particle_steps))
     traffic = prof.get('k_const_fused_bytes_per_launch')
-    insts = prof.get('k_const_fused_valu_wave_insts_per_launch')
-    atoms = prof.get('k_const_fused_atomic_requests_per_launch')
+    mix = model['per_wave_trip']
+    per_trip = mix['fp64'] + mix['transcendental'] + mix['valu32']
+    if wave_trips:
+        insts, insts_src = wave_trips*per_trip, 'wave trips counted in this run x the static ' \
+            f'per-trip VALU mix of profiles/cost_model.json ({per_trip} instructions)'
+    else:
+        insts = prof.get('k_const_fused_valu_wave_insts_per_launch')
+        insts = insts*scale if insts else None
+        insts_src = 'profiles/' + str(prof.get('tag', '')) + '_pmc.json, scaled'
+    if binned is not None:
+        atoms, atoms_src = float(binned), 'samples binned in this run (one pair-atomic each)'
+    else:
+        atoms = prof.get('k_const_fused_atomic_requests_per_launch')
+        atoms = atoms*scale if atoms else None
+        atoms_src = 'profiles/' + str(prof.get('tag', '')) + '_pmc.json, scaled'
     if not (insts and atoms):
         return traffic, None
-    mix = model['per_wave_trip']
     slots = (mix['fp64'] + mix['transcendental']*model['slot_cost']['transcendental']
              + mix['valu32']*model['slot_cost']['valu32'])
-    per_inst = slots/(mix['fp64'] + mix['transcendental'] + mix['valu32'])
+    per_inst = slots/per_trip
     clock = (clock_mhz or model['profile_clock_mhz'])*1e6
     n_simd = 256*4
-    valu_floor_ms = insts*scale*per_inst*4/(n_simd*clock)*1e3
-    atomic_floor_ms = atoms*scale/model['atomic_requests_per_s']*1e3
-    secondary = {'valu_wave_insts_per_launch': insts*scale,
+    valu_floor_ms = insts*per_inst*4/(n_simd*clock)*1e3
+    atomic_floor_ms = atoms/model['atomic_requests_per_s']*1e3
+    secondary = {'valu_wave_insts_per_launch': insts, 'valu_wave_insts_source': insts_src,
+                 'wave_trips': wave_trips,
+                 'lanes_active': particle_steps/(64.0*wave_trips) if wave_trips else None,
                  'issue_slots_per_instruction': per_inst, 'clock_mhz': clock/1e6,
                  'clock_source': 'in-kernel stamps, this run' if clock_mhz else 'profile',
                  'valu_issue_floor_ms': valu_floor_ms, 'valu_issue_frac': valu_floor_ms/k_ms,
                  'valu_busy_frac_pmc': prof.get('k_const_fused_valu_busy_frac'),
-                 'atomic_requests_per_launch': atoms*scale, 'atomic_floor_ms': atomic_floor_ms,
-                 'atomic_frac': atomic_floor_ms/k_ms,
-                 'source': 'profiles/' + str(prof.get('tag', '')) + '_pmc.json, '
-                           'profiles/cost_model.json'}
+                 'valu_busy_frac_pmc_from_profile': True,
+                 'atomic_requests_per_launch': atoms, 'atomic_requests_source': atoms_src,
+                 'atomic_floor_ms': atomic_floor_ms, 'atomic_frac': atomic_floor_ms/k_ms,
+                 'source': 'this run (wave trips, binned samples, clock); profiles/' +
+                           str(prof.get('tag', '')) + '_pmc.json for valu_busy_frac_pmc; '
+                           'profiles/cost_model.json for the per-trip mix and slot costs'}
     return (traffic*scale if traffic else None), secondary
 
 
@@ -453,6 +474,7 @@ def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
     elapsed, kernel_ms = timed(comm, args.steps)
 
     ctr = ctx.counters()
+    trips = ctx.wave_trips() if hasattr(ctx, 'wave_trips') else None
     if comm:
         elapsed = ctx.allreduce_max(elapsed)
         work_all = ctx.allreduce_sum(float(ctr['particle_steps']))
@@ -522,7 +544,8 @@ def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
         clock_mhz = ctx.shader_clock_mhz() if extras and hasattr(ctx, 'shader_clock_mhz') else None
         copy_gbs = ctx.stream_copy_gbs() if extras and hasattr(ctx, 'stream_copy_gbs') else None
         traffic, secondary = (None, None) if variable else \
-            profile_ceilings(k_ms, ctr['particle_steps'], clock_mhz)
+            profile_ceilings(k_ms, ctr['particle_steps'], clock_mhz, trips,
+                             ctr.get('samples_binned'))
         unit = 'rk5 attempts/s' if variable else 'particle*steps/s'
         if variable:
             workload = (f'Na at Mercury (taa 1.3), gravity+radpres+photoionisation, {packets} '
@@ -552,7 +575,11 @@ def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'peak_measured': copy_gbs,
                          'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
                          'frac_of_measured_peak': achieved/copy_gbs if copy_gbs else None,
-                         'traffic': traffic, 'kernel': kernel, 'kernel_ms': k_ms,
+                         # MI355X_MICROARCH.md's own float4-copy measurement, for a box-independent
+                         # reading of the same fraction
+                         'peak_guide_copy': GUIDE_COPY_GBS, 'frac_of_guide_copy': achieved/GUIDE_COPY_GBS,
+                         'traffic': traffic, 'traffic_from_profile': traffic is not None,
+                         'kernel': kernel, 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_particle_step': ALGO_BYTES_PER_PARTICLE_STEP,
                          'binding': 'fp64 VALU issue', 'binding_ceilings': secondary,
                          'note': 'achieved/peak/frac are the HBM contract of SURVEY.md 8(d) '

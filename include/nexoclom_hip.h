@@ -108,7 +108,9 @@ typedef struct nxc_counters {
     uint64_t bad_step;       /* step size <= 0 or not finite (variable driver)                   */
     uint64_t neg_frac;       /* accepted step with frac < 0 (variable driver, Output.py:287)     */
     uint64_t unfinished;     /* packets stopped by max_steps before reaching their end time      */
-    uint64_t reserved;
+    uint64_t wave_trips;     /* measurement, not a result: trips of a wave through the persistent
+                                step loop (64 lanes each); particle_steps / (64 wave_trips) is the
+                                share of lanes that held a live packet.  Depends on scheduling. */
 } nxc_counters;
 
 typedef struct nxc_handle nxc_handle;

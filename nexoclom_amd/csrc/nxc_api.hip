@@ -1704,7 +1704,7 @@ int nxc_counters_get(nxc_handle *h, nxc_counters *out)
     out->bad_step = c.bad_step;
     out->neg_frac = c.neg_frac;
     out->unfinished = c.unfinished;
-    out->reserved = 0;
+    out->wave_trips = c.wave_trips;
     return NXC_OK;
 }
 
@@ -2606,7 +2606,9 @@ int nxc_stream_copy_gbs(nxc_handle *h, int64_t bytes, int reps, double *gbs)
     if (e == hipSuccess) e = hipEventCreate(&b);
     for (int r = 0; r <= reps && e == hipSuccess; r++) {         // first round warms up
         e = hipEventRecord(a, h->stream);
-        hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)(h->n_cu * 32)), dim3(NXC_BLOCK), 0, h->stream,
+        const int64_t per_block = (int64_t)NXC_BLOCK * NXC_COPY_UNROLL;
+        hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n16 + per_block - 1) / per_block)),
+                           dim3(NXC_BLOCK), 0, h->stream,
                            reinterpret_cast<const nxc_v2d *>(buf),
                            reinterpret_cast<nxc_v2d *>(buf + (size_t)n16 * 16), n16);
         if (e == hipSuccess) e = hipGetLastError();

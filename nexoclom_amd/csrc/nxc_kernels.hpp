@@ -21,6 +21,7 @@
 struct DevCounters {
     unsigned long long particle_steps, samples, samples_binned, nonfinite, bad_step, neg_frac,
         unfinished, queue_head;
+    unsigned long long wave_trips;   // trips of a wave through a persistent step loop (measurement)
 #ifdef NXC_STAMPS               // diagnostic build only: summed s_memtime shares of the loop segments
     unsigned long long stamp[8];
 #endif
@@ -472,7 +473,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
     bool has = false, fresh = false;
     long long id = -1, row0 = 0, nrow = 0;
     double lossfrac = 0.0;
-    unsigned my_overrun = 0;
+    unsigned my_overrun = 0, my_trips = 0;          // my_trips is wave-uniform: a scalar add per trip
     int k = 0, nbounce = 0;
     const int n_it = n_iter > 0x7fffffffll ? 0x7fffffff : (int)n_iter;
     double s[8], d[8];
@@ -495,6 +496,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 #endif
         if (got >= 0) { id = got; k = 0; has = true; fresh = true; nbounce = 0; lossfrac = 0.0; }
         if (__ballot(has) == 0) break;
+        my_trips++;
         NXC_STAMP(0);                                  // refill
         int p = -1;
         double rv = 0.0, fw = 0.0;
@@ -606,6 +608,7 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
         }
     }
     flush_counter(&ctr->particle_steps, my_steps);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->wave_trips, (unsigned long long)my_trips);
     if (ROWS) flush_counter(&ctr->unfinished, my_overrun);
     if (STREAMED && q.stalled && (threadIdx.x & 63) == 0) atomicAdd(&ctr->unfinished, 1ull);
     if (IMAGE) {
@@ -639,6 +642,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
     bool has = false;
     long long id = -1, it = 0;
+    unsigned my_trips = 0;
     double s[8], hs = 1000.0;
     for (;;) {
         const long long got = q.refill(!has, stage_off, s);
@@ -646,6 +650,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             id = got; it = 0; hs = 1000.0; has = true;
         }
         if (__ballot(has) == 0) break;
+        my_trips++;
         if (has) {
             bool done = !(s[0] > resolution && s[7] > 0.0);
             if (!done && it >= max_steps) { my_unfinished++; done = true; }
@@ -700,6 +705,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
         }
     }
     flush_counter(&ctr->particle_steps, my_steps);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->wave_trips, (unsigned long long)my_trips);
     flush_counter(&ctr->nonfinite, my_nonfinite);
     flush_counter(&ctr->bad_step, my_bad);
     flush_counter(&ctr->neg_frac, my_neg);
@@ -1042,23 +1048,26 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
 
 // ---- measurement helpers (bench.py's roofline object) --------------------------------------------
 // Streaming copy, 16 bytes per lane: the box's own HBM ceiling next to the 8 TB/s of the data sheet.
+// One workgroup copies four consecutive 4 KB runs, all four loads of a lane in flight before its
+// first store, non-temporal both ways: 6.25 TB/s on the boxes of this pool, which is the 6.29 of
+// MI355X_MICROARCH.md's float4 copy (tools/ubench_copy.hip: a persistent grid-stride loop -- what
+// this kernel was until round 4 -- stops at 4.5-5.0, hipMemcpyAsync at 4.8).
+constexpr int NXC_COPY_UNROLL = 4;
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_stream_copy(const nxc_v2d *__restrict__ src, nxc_v2d *__restrict__ dst, int64_t n16)
 {
-    // four independent 16-byte loads in flight per lane before the first store
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const nxc_v2d a = __builtin_nontemporal_load(src + i);
-        const nxc_v2d b = __builtin_nontemporal_load(src + i + stride);
-        const nxc_v2d c = __builtin_nontemporal_load(src + i + 2 * stride);
-        const nxc_v2d d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    const int64_t base = (int64_t)blockIdx.x * (NXC_BLOCK * NXC_COPY_UNROLL) + threadIdx.x;
+    nxc_v2d r[NXC_COPY_UNROLL];
+#pragma unroll
+    for (int u = 0; u < NXC_COPY_UNROLL; u++) {
+        const int64_t i = base + (int64_t)u * NXC_BLOCK;
+        if (i < n16) r[u] = __builtin_nontemporal_load(src + i);
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
+#pragma unroll
+    for (int u = 0; u < NXC_COPY_UNROLL; u++) {
+        const int64_t i = base + (int64_t)u * NXC_BLOCK;
+        if (i < n16) __builtin_nontemporal_store(r[u], dst + i);
+    }
 }
 
 // Shader clock under fp64 load: every wave runs `iters` rounds of eight independent fp64 fma
@@ -1696,7 +1705,7 @@ __global__ void k_sum_counters(const DevCounters *__restrict__ pieces, int n, De
             t.particle_steps += pieces[p].particle_steps; t.samples += pieces[p].samples;
             t.samples_binned += pieces[p].samples_binned; t.nonfinite += pieces[p].nonfinite;
             t.bad_step += pieces[p].bad_step; t.neg_frac += pieces[p].neg_frac;
-            t.unfinished += pieces[p].unfinished;
+            t.unfinished += pieces[p].unfinished; t.wave_trips += pieces[p].wave_trips;
         }
         *out = t;
     }

@@ -106,7 +106,7 @@ class nxc_bodies_desc(C.Structure):
 class nxc_counters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in
                 ('particle_steps', 'samples', 'samples_binned', 'nonfinite', 'bad_step',
-                 'neg_frac', 'unfinished', 'reserved')]
+                 'neg_frac', 'unfinished', 'wave_trips')]
 
 
 _lib = None
@@ -450,7 +450,15 @@ class Context:
     def counters(self):
         c = nxc_counters()
         self._check(self.lib.nxc_counters_get(self._h, C.byref(c)))
-        return {k: int(getattr(c, k)) for k, _ in nxc_counters._fields_ if k != 'reserved'}
+        return {k: int(getattr(c, k)) for k, _ in nxc_counters._fields_ if k != 'wave_trips'}
+
+    def wave_trips(self):
+        """Trips of a wave through the persistent step loop in the last integrate call: a
+        measurement (it depends on how the lanes happened to be refilled), kept out of
+        ``counters()`` -- whose entries are results and repeat exactly."""
+        c = nxc_counters()
+        self._check(self.lib.nxc_counters_get(self._h, C.byref(c)))
+        return int(c.wave_trips)
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
