@@ -110,7 +110,7 @@ class Input:
 
     def run(self, npackets, packs_per_it=None, overwrite=False, compress=True,
             distribute=False, seed=None, *, device=0, keep_trajectory=True, context=None,
-            sampler='numpy', batch=True, generator='philox'):
+            sampler='numpy', batch=True, generator='philox', cp=None):
         """Integrate until the catalogue holds ``npackets`` packets (Input.py:175-268).
 
         Every pass plans ``ceil(todo / size)`` Outputs of ``size = min(todo, chunk_size)``
@@ -127,14 +127,32 @@ class Input:
         upload, one launch of each kernel over all their packets (Output.integrate_batch), each
         Output then owning its slice of the rows, which stay in HBM for produce_image /
         LOSResult.  With a ``savepath`` the files are written by a worker thread beside the next
-        launch (``wait()`` joins it)."""
+        launch (``wait()`` joins it).
+
+        ``cp`` (a distributed.ControlPlane of several ranks, one process per GPU): the run is
+        SHARED.  The plan -- how many Outputs, of which size, from which seed or index range -- is
+        the single-process plan; rank r makes the Outputs ``shard_range(passes, r, world)`` of
+        every pass and catalogues only those, so Output k is the same Output whatever the number
+        of ranks, and the union of the ranks' catalogues is the single-process catalogue.  The
+        packet count that ends the run is summed over the ranks.  ``produce_image(..., cp=cp)`` and
+        ``LOSResult.simulate_data_from_inputs(..., cp=cp)`` then sum over the ranks what the
+        reference sums over the files (ModelImage.py:96-98, LOSResult.py:264-266)."""
         from .Output import Output
         started = time.time()
+        rank, world = (cp.rank, cp.world) if cp is not None else (0, 1)
+        if world > 1 and seed is None and sampler != 'device':
+            # the host sampler seeds Output k with seed + k: without a seed the ranks would not
+            # make the Outputs of one run
+            seed = int.from_bytes(cp.bcast_bytes(os.urandom(4), 4), 'little')
+
+        def report():
+            local = self._report()
+            return local if world == 1 else int(round(cp.reduce(float(local), 'SUM')))
         if distribute in (True, 'delay', 'delayed'):
             assert False, 'Dont do this'         # the reference's dask path is disabled too
         if overwrite:
             self.delete_files()
-        have = self._report()
+        have = report()
         want = int(npackets)
         made = 0
         drawn = have                             # device sampler: next free global packet index
@@ -152,6 +170,8 @@ class Input:
         if seed is None and sampler == 'device':
             from .Output import fresh_key
             seed = fresh_key()                   # one key for the whole (unseeded) run
+            if world > 1:
+                seed = int.from_bytes(cp.bcast_bytes(seed.to_bytes(8, 'little'), 8), 'little')
         while have < want:
             todo = want - have
             size = min(todo, self.chunk_size(packs_per_it))
@@ -159,6 +179,14 @@ class Input:
             print('Running Model')
             print(f'Will complete {passes} iterations of {size} packets.')
             number = 0
+            stop = passes
+            if world > 1:
+                # this rank's Outputs of the pass; the counters move as if the others were made here
+                from .distributed import shard_range
+                number, stop = shard_range(passes, rank, world)
+                made += number
+                drawn += size*number
+                print(f'Rank {rank} of {world}: iterations {number + 1} to {stop}.')
             ahead = None                         # the next launch group's Outputs, being drawn
             pool = None
 
@@ -171,12 +199,12 @@ class Input:
                                     integrate=False, save=False, seed=s_) for s_ in seeds]
 
             try:
-                while number < passes:
+                while number < stop:
                     tick = time.time()
                     # as many Outputs per launch as HBM takes (rows: nsteps records per packet at
                     # most, far fewer in practice; the row store spills its oldest runs to the host)
                     limit = self._group_limit(size, context) if together else 1
-                    group = min(passes - number, limit)
+                    group = min(stop - number, limit)
                     outs = []
                     if together and sampler == 'numpy' and (group > 1 or ahead is not None):
                         if pool is None:
@@ -185,7 +213,7 @@ class Input:
                         futures = ahead if ahead is not None else draw_ahead(made, group)
                         group = len(futures)
                         # ... and the group after this one while this one is integrated
-                        later = min(passes - number - group, self._group_limit(size, context))
+                        later = min(stop - number - group, self._group_limit(size, context))
                         ahead = draw_ahead(made + group, later) if later > 0 else None
                         outs = [f.result() for f in futures]
                         number += group
@@ -219,7 +247,9 @@ class Input:
             finally:
                 if pool is not None:
                     pool.shutdown(cancel_futures=True)
-            have = self._report()
+            made += passes - stop                # the Outputs of the ranks after this one
+            drawn += size*(passes - stop)
+            have = report()
         self.wait()                              # files of this run are on disk when it returns
         print(f'Model run completed in {time.time() - started:.2f} sec.')
 
@@ -284,6 +314,19 @@ class Input:
         print(f'Found {len(files)} files with {packets} packets.')
         return packets
 
-    def produce_image(self, format_, overwrite=False, distribute=None, **kwargs):
+    def produce_image(self, format_, overwrite=False, distribute=None, *, cp=None, reduce='rccl',
+                      **kwargs):
+        """Input.py:270-272.  ``cp``: the control plane of a shared run (``run(..., cp=cp)``):
+        every rank bins the Outputs of its own catalogue and the image pairs and source totals
+        are summed over the ranks (reduce='rccl': one ncclAllReduce; 'host': over the control
+        plane, for tests) -- every rank gets the image of the whole run."""
         from .ModelImage import ModelImage
-        return ModelImage(self, format_, overwrite=overwrite, distribute=distribute, **kwargs)
+        if cp is None or cp.world == 1:
+            return ModelImage(self, format_, overwrite=overwrite, distribute=distribute, **kwargs)
+        from .distributed import guarded, merge_catalogue
+        image = ModelImage(self, format_, overwrite=overwrite, distribute=distribute,
+                           finalize=False, **kwargs)
+        with guarded(cp, image.context()):
+            merge_catalogue(image, cp, image.context(), reduce)
+        image.finalize()
+        return image

@@ -168,20 +168,37 @@ class LOSResult(ModelResult):
             res[key] = pd.Series(res[key], index=spectra.index)
         return res
 
-    def simulate_data_from_inputs(self, scdata, distribute=None):
+    def simulate_data_from_inputs(self, scdata, distribute=None, *, cp=None, reduce='rccl'):
         """LOSResult.py:202-276: sum the iterations of every catalogued Output, then scale to kR
-        for a source rate of 1e23 atoms/s."""
+        for a source rate of 1e23 atoms/s.  ``cp``: the control plane of a shared run
+        (``Input.run(..., cp=cp)``): this rank's catalogue is its share of the Outputs; the
+        per-spectrum radiances and packet counts and the source totals are summed over the ranks
+        where the reference sums over the files (LOSResult.py:264-266) -- S + S + 2 doubles, one
+        all-reduce.  ``iterations`` (with their `included` flags) stay those of the local Outputs."""
         if distribute in (True, 'delay', 'delayed'):
             assert False, "Don't do this"
         self.outid, self.outputfiles, self.npackets, self.totalsource = self.inputs.search()
         print(f'LOSResult: {len(self.outid)} output files found.')
-        if self.npackets == 0:
+        shared = cp is not None and cp.world > 1
+        if self.npackets == 0 and not shared:
             raise RuntimeError('No packets found for these Inputs.')
         self.iterations = [self.compute_iteration(run, scdata) for run in self.inputs._catalogue]
         for it in self.iterations:
             assert len(it['radiance']) == len(scdata.data)
             self.radiance += it['radiance']
             self.npackets_los += it['npackets']
+        if shared:
+            from .distributed import allreduce_small, guarded
+            S = len(scdata.data)
+            with guarded(cp, self.context()):
+                both = allreduce_small(np.concatenate([
+                    np.asarray(self.radiance, dtype=float), np.asarray(self.npackets_los, dtype=float),
+                    [float(self.totalsource), float(self.npackets)]]), cp, self.context(), reduce)
+            self.radiance[:] = both[:S]
+            self.npackets_los[:] = np.rint(both[S:2*S]).astype(self.npackets_los.dtype)
+            self.totalsource, self.npackets = float(both[2*S]), int(round(both[2*S + 1]))
+            if self.npackets == 0:
+                raise RuntimeError('No packets found for these Inputs.')
         per_second = self.totalsource / self.inputs.options.endtime.value
         self.atoms_per_packet = 1e23 / per_second
         self.radiance *= self.atoms_per_packet/1e3      # kR

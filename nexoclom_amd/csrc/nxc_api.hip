@@ -1040,7 +1040,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
     // ... | per-wave candidate queues
     const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double) +
-                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOSQ_BYTES;
+                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES;
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
     // device scratch: blob | sc | ladder | radiance | npackets | included | used
@@ -1068,10 +1068,15 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
         const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
         int gx = flat_grid(h, (P + NXC_LOS_BLOCK - 1) / NXC_LOS_BLOCK, NXC_LOS_THREADS);
         if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
+        // every wave owns a contiguous range of rows (it follows the packets through them)
+        const int64_t n_waves = (int64_t)gx * (NXC_LOS_THREADS / 64);
+        const int64_t rows_per_wave = ((P + n_waves - 1) / n_waves + 63) / 64 * 64;
+        if (rows_per_wave >= (int64_t(1) << 27))
+            return fail(NXC_ERR_ARG, "too many samples for one line-of-sight call (2^27 per wave)");
         if ((rc = begin_timed(h))) return rc;
         hipLaunchKernelGGL((k_los<T, I>), dim3(gx, tiles), dim3(NXC_LOS_THREADS), lds, st, K, base + o_blob,
                            (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc), P,
-                           dx, dy, dz, dvy, dfrac, d_index,
+                           rows_per_wave, dx, dy, dz, dvy, dfrac, d_index,
                            reinterpret_cast<const double *>(base + o_lad),
                            reinterpret_cast<double *>(base + o_rad),
                            reinterpret_cast<unsigned long long *>(base + o_np),

@@ -1221,11 +1221,11 @@ NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spec
     }
 }
 
-// Per-wave queue of (block, spectrum) candidates between the sphere test and the pair tests: a
+// Per-wave queue of (block, spectrum) candidates between the sphere tests and the pair tests: a
 // ring in LDS, filled in lane order (ballot + prefix rank), emptied 64 at a time, so that the pair
-// tests run with full waves although only a few per cent of the sphere tests pass.  All calls are
-// wave-uniform.
-constexpr int NXC_LOSQ_SLOTS = 256;
+// tests run with full waves although only one sphere test in a thousand passes.  All calls are
+// wave-uniform.  An entry names its block as (first row << 4 | rows).
+constexpr int NXC_LOSQ_SLOTS = 128;                   // < 64 waiting + at most 64 new
 constexpr int NXC_LOSQ_BYTES = NXC_LOSQ_SLOTS * (8 + 4);
 struct LosQueue {
     int head = 0, tail = 0;
@@ -1261,29 +1261,86 @@ struct LosQueue {
     }
 };
 
+// Wave-wide exclusive prefix sum / prefix maximum of one int per lane (six shuffle steps);
+// `total` receives the reduction over all 64 lanes.
+NXC_DEV int wave_excl_sum(int v, int &total)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
+}
+NXC_DEV int wave_excl_max(int v, int &total)
+{
+    const int lane = threadIdx.x & 63;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl = incl > o ? incl : o;
+    }
+    total = __builtin_amdgcn_readlane(incl, 63);
+    const int before = __shfl_up(incl, 1, 64);
+    return lane == 0 ? -1 : before;
+}
+
+// Can any point of the sphere (centre c, radius R) lie in the cone of spectrum sp (apex a, unit
+// axis b, half-angle dphi, between the apex and the cut-off sp[6])?  Only if the centre's distance
+// from the axis is at most R + (q_c + R) tan dphi, q_c = (c - a).b, and q_c + R > 0,
+// q_c - R < cut-off (the distance to a line and q are 1-Lipschitz).  Conservative: with slack for
+// the rounding of perp2, whose terms cancel when the centre is near the line; R = +inf (a block
+// with a non-finite coordinate, or culling switched off) passes every cone, R < 0 (no block) none.
+NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy, double cz, double R,
+                             double tan_dphi)
+{
+    const double rx = cx - sp[0], ry = cy - sp[1], rz = cz - sp[2];
+    const double qc = (rx * sp[3] + ry * sp[4]) + rz * sp[5];
+    const double perp2 = ((rx * rx + ry * ry) + rz * rz) - qc * qc;
+    const double lim = R + (qc + R) * tan_dphi;
+    return (R >= 0.0) && (qc + R > 0.0) && (qc - R < sp[6]) &&
+           !(perp2 > lim * lim * (1.0 + 1e-6) + 1e-9);
+}
+
 // T: double, or float for samples as Output.save() stores them (widened exactly, like restore());
 // I: the type of the packet-index column (int64, or int32 as save() stores it).
 //
-// A thread owns BLOCKS of NXC_LOS_BLOCK consecutive stored samples.  The rows of an Output are
-// packet-major (Output.py:435-449), so a block is a short piece of one packet's trajectory: a few
-// steps long, a small sphere.  The block's bounding sphere (centre c, radius R) is tested against
-// every cone of the tile first: a sample can only lie in the cone of half-angle dphi around the
-// line a + t b (|b| = 1) if the centre's distance from that line is at most
-// R + (q_c + R) tan dphi, q_c = (c - a).b, and q_c + R > 0, q_c - R < cut-off (the distance to a
-// line and q are 1-Lipschitz).  The (block, spectrum) candidates that pass -- a few per cent --
-// go through a per-wave LDS queue, so that their samples meet los_pair with full waves;
-// everything else costs one sphere test per 8 pairs.  K.cull = 0 (boresights that are not unit
-// vectors) sends every block through.
-// 512 threads: two workgroups (50 KB of LDS each) = 16 waves per CU; with 256 it was 12, and the
-// kernel -- half culling loop, half candidate drains with dependent global loads -- ran 28 % longer
-// (reading the next spectrum from LDS ahead of the queue's fence: 6 % at 256 threads, nothing at 512)
+// Two levels of culling in front of the exact pair test, both on bounding spheres.
+//
+// BLOCKS.  The rows of an Output are packet-major (Output.py:435-449), so consecutive rows are
+// consecutive steps of one packet -- until the packet ends.  A block is at most NXC_LOS_BLOCK
+// consecutive rows OF ONE PACKET (the index column says where packets end): a short piece of one
+// trajectory, a small sphere.  (Blocks cut from the row numbers alone straddle packet ends -- one
+// block in six for the bench cloud -- and such a block is as large as the distance between the two
+// packets: 2.5 % of all (block, cone) tests passed, against 0.15 % for blocks that respect the
+// packets.)  A wave owns a contiguous range of rows; it reads the index column 256 rows at a time,
+// finds the packet starts with a prefix maximum across its lanes, and files the block descriptors
+// ((row - range start) << 4 | rows) in a ring in LDS from which it takes 64 at a time: every lane
+// holds a block whatever the packet lengths.  Without an index column the rows are one packet.
+//
+// GROUPS.  The 8 blocks held by 8 adjacent lanes (up to 64 rows, mostly one packet) form a group
+// with a bounding sphere of its own.  The 8 lanes share the group's cone tests -- lane i tests the
+// spectra i, i + 8, ... of the tile: 16 tests per lane instead of 128 -- and only the (group,
+// spectrum) pairs that pass (7 % for the bench cloud) are looked at block by block: 8 pairs per
+// wave instruction, one lane per (pair, block).  Sphere tests per 8 rows: 128 per tile before,
+// about 16 + 9 now.  What passes the block test -- one (block, spectrum) pair in 700 -- goes through
+// the per-wave LDS queue, so that its rows meet los_pair with full waves.
+// K.cull = 0 (boresights that are not unit vectors) gives every block an infinite radius.
+constexpr int NXC_LOS_RING = 512;        // block descriptors waiting per wave (< 64 + 256 new)
+constexpr int NXC_LOS_FORM = 256;        // rows whose packet ids are examined at a time: 4 per lane
+constexpr int NXC_LOS_PAIRS = 512;       // (group, spectrum) survivors of 8 tests per lane
+constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32 + 64 * 4 + NXC_LOS_PAIRS * 2;
 #ifndef NXC_LOS_THREADS
 #define NXC_LOS_THREADS 512
 #endif
 template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_LOS_THREADS)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
-      const double *__restrict__ sc, int64_t P, const T *__restrict__ x,
+      const double *__restrict__ sc, int64_t P, int64_t rows_per_wave, const T *__restrict__ x,
       const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ vy,
       const T *__restrict__ frac, const I *__restrict__ index,
       const double *__restrict__ ladder, double *__restrict__ radiance,
@@ -1291,6 +1348,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
       long long used_cap, long long *__restrict__ used_pairs,
       unsigned long long *__restrict__ n_used, DevCounters *__restrict__ ctr)
 {
+    static_assert(NXC_LOS_BLOCK <= 15, "a block descriptor keeps its row count in four bits");
     stage_tables(blob, stage_bytes);
     const int64_t s0 = (int64_t)blockIdx.y * NXC_LOS_TILE;
     const int ns = (int)((S - s0) < NXC_LOS_TILE ? (S - s0) : NXC_LOS_TILE);
@@ -1301,16 +1359,25 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     }
     __syncthreads();
     const double rs_1e6 = nxc_recip_seed(1e6);
-    unsigned long long my_pairs = 0, my_nonfinite = 0;
-    const int64_t nblocks = (P + NXC_LOS_BLOCK - 1) / NXC_LOS_BLOCK;
-    const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + (int)(threadIdx.x >> 6) * NXC_LOSQ_BYTES;
+    unsigned long long my_pairs = 0, my_nonfinite = 0, my_tests = 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + wid * NXC_LOS_WAVE_BYTES;
+    unsigned *const ring = reinterpret_cast<unsigned *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
+    double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4);
+    unsigned *const sdesc = reinterpret_cast<unsigned *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32);
+    unsigned short *const pairs =
+        reinterpret_cast<unsigned short *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32 + 64 * 4);
+    // this wave's rows
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const int64_t lo = wave * rows_per_wave < P ? wave * rows_per_wave : P;
+    const int64_t hi = lo + rows_per_wave < P ? lo + rows_per_wave : P;
     LosQueue queue;
     auto drain = [&]() {               // up to 64 queued candidates, one per lane
         long long qb = 0;
         int qj = 0;
         if (queue.pop(qoff, qb, qj)) {
-            const int64_t q0 = qb * NXC_LOS_BLOCK;
-            const int qn = (int)((P - q0) < NXC_LOS_BLOCK ? (P - q0) : NXC_LOS_BLOCK);
+            const int64_t q0 = qb >> 4;
+            const int qn = (int)(qb & 15);
             for (int s_ = 0; s_ < qn; s_++) {
                 const int64_t p = q0 + s_;
                 los_pair<T, I>(K, tile + qj * 8, s0 + qj, p, (double)x[p], (double)y[p], (double)z[p],
@@ -1319,16 +1386,70 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             }
         }
     };
-    // wave-uniform trip count (the queue is wave-cooperative); the last trip is ragged
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < nblocks;
-         base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t blk = base + threadIdx.x;
-        const bool has = blk < nblocks;
-        double cx = 0, cy = 0, cz = 0, R = 0;
-        bool finite = true;
+    int64_t next = lo;                 // first row whose packet id has not been looked at
+    int64_t carry = lo;                // where the packet that row `next - 1` belongs to starts
+    int rhead = 0, rtail = 0;          // the descriptor ring (wave-uniform)
+    for (;;) {
+        // ---- block descriptors: until 64 are waiting or the range is used up ---------------------
+        while (rtail - rhead < 64 && next < hi) {
+            const int64_t r0 = next + 4 * lane;
+            long long id[4] = {0, 0, 0, 0};
+            bool bnd[4];
+            long long prev = 0;
+            if (index) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (r0 + k < hi) id[k] = (long long)index[r0 + k];
+                if (r0 > lo && r0 < hi) prev = (long long)index[r0 - 1];
+            }
+            int last = -1;             // last packet start among my rows, relative to `next`
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bnd[k] = r0 + k < hi && (r0 + k == lo || (index && id[k] != (k ? id[k - 1] : prev)));
+                if (bnd[k]) last = 4 * lane + k;
+            }
+            int wave_last;
+            const int before = wave_excl_max(last, wave_last);
+            int64_t start = before >= 0 ? next + before : carry;   // start of the packet of row r0 - 1
+            unsigned d[4] = {0, 0, 0, 0};
+            bool emit[4];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t r = r0 + k;
+                if (bnd[k]) start = r;
+                emit[k] = r < hi && ((r - start) & (NXC_LOS_BLOCK - 1)) == 0;
+                if (emit[k]) {
+                    int n = 1;         // rows of this block: same packet, inside the range
+                    while (n < NXC_LOS_BLOCK && r + n < hi &&
+                           (!index || (long long)index[r + n] == id[k]))
+                        n++;
+                    d[k] = (unsigned)(r - lo) << 4 | (unsigned)n;
+                    cnt++;
+                }
+            }
+            int total;
+            int at = rtail + wave_excl_sum(cnt, total);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (emit[k]) ring[at++ & (NXC_LOS_RING - 1)] = d[k];
+            rtail += total;
+            if (wave_last >= 0) carry = next + wave_last;
+            next += NXC_LOS_FORM;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (rtail == rhead) break;
+        // ---- one trip: 64 blocks (fewer at the end of the range), one per lane ------------------
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int m = rtail - rhead < 64 ? rtail - rhead : 64;
+        const bool has = lane < m;
+        unsigned desc = 0;
+        double cx = 0, cy = 0, cz = 0, R = -1.0;
         if (has) {
-            const int64_t p0 = blk * NXC_LOS_BLOCK;
-            const int nb = (int)((P - p0) < NXC_LOS_BLOCK ? (P - p0) : NXC_LOS_BLOCK);
+            desc = ring[(rhead + lane) & (NXC_LOS_RING - 1)];
+            const int64_t p0 = lo + (desc >> 4);
+            const int nb = (int)(desc & 15u);
             // bounding sphere: centre of the bounding box, largest distance from it
             double lox = (double)x[p0], hix = lox, loy = (double)y[p0], hiy = loy, loz = (double)z[p0], hiz = loz;
             for (int s_ = 1; s_ < nb; s_++) {
@@ -1347,25 +1468,72 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                 R2 = __builtin_fmax(R2, e2);
             }
             // a non-finite coordinate must reach los_pair (it decides such samples like the reference)
-            finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
-            R = finite ? __builtin_sqrt(R2) * (1.0 + 1e-12) : 0.0;
+            const bool finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
+            if (finite && K.cull) R = __builtin_sqrt(R2) * (1.0 + 1e-12);
+            else { cx = cy = cz = 0.0; R = __builtin_inf(); }
         }
-        for (int j = 0; j < ns; j++) {
-            bool hit = has;
-            if (has && K.cull && finite) {
-                const double *sp = tile + j * 8;
-                const double rx = cx - sp[0], ry = cy - sp[1], rz = cz - sp[2];
-                const double qc = (rx * sp[3] + ry * sp[4]) + rz * sp[5];
-                const double perp2 = ((rx * rx + ry * ry) + rz * rz) - qc * qc;
-                const double lim = R + (qc + R) * K.tan_dphi;
-                // (slack for the rounding of perp2, whose terms cancel when the centre is near the line)
-                hit = (qc + R > 0.0) && (qc - R < sp[6]) && !(perp2 > lim * lim * (1.0 + 1e-6) + 1e-9);
+        rhead += m;
+        sph[4 * lane] = cx; sph[4 * lane + 1] = cy; sph[4 * lane + 2] = cz; sph[4 * lane + 3] = R;
+        sdesc[lane] = desc;
+        // the group's sphere: centre of the box of its blocks' centres, radius to the farthest
+        // point of any of its blocks (three butterfly steps inside the 8 lanes)
+        const double big = 1.7976931348623157e308;
+        double blx = has ? cx : big, bhx = has ? cx : -big, bly = has ? cy : big, bhy = has ? cy : -big,
+               blz = has ? cz : big, bhz = has ? cz : -big;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            blx = __builtin_fmin(blx, __shfl_xor(blx, off, 64)); bhx = __builtin_fmax(bhx, __shfl_xor(bhx, off, 64));
+            bly = __builtin_fmin(bly, __shfl_xor(bly, off, 64)); bhy = __builtin_fmax(bhy, __shfl_xor(bhy, off, 64));
+            blz = __builtin_fmin(blz, __shfl_xor(blz, off, 64)); bhz = __builtin_fmax(bhz, __shfl_xor(bhz, off, 64));
+        }
+        const double gx_ = 0.5 * (blx + bhx), gy_ = 0.5 * (bly + bhy), gz_ = 0.5 * (blz + bhz);
+        double GR = -1.0;
+        if (has) {
+            const double ex = cx - gx_, ey = cy - gy_, ez = cz - gz_;
+            GR = (__builtin_sqrt((ex * ex + ey * ey) + ez * ez) + R) * (1.0 + 1e-12);
+        }
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) GR = __builtin_fmax(GR, __shfl_xor(GR, off, 64));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- group tests (8 spectra per lane and half), then their survivors block by block ------
+        const int grp = lane >> 3, sub = lane & 7;
+        for (int half = 0; half < 2; half++) {
+            int npair = 0;
+#pragma unroll
+            for (int t = 0; t < NXC_LOS_TILE / 16; t++) {
+                const int j = sub + 8 * (t + half * (NXC_LOS_TILE / 16));
+                const bool hit = j < ns && los_sphere_hits(tile + j * 8, gx_, gy_, gz_, GR, K.tan_dphi);
+                my_tests += j < ns && GR >= 0.0;
+                const unsigned long long mask = __ballot(hit);
+                if (hit) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(grp << 7 | j);
+                npair += __popcll(mask);
             }
-            queue.push(hit, blk, j, qoff);
-            if (queue.waiting() >= 64) drain();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int base = 0; base < npair; base += 8) {
+                const int at = base + grp;                    // eight pairs per wave instruction
+                bool hit = false;
+                int j = 0;
+                unsigned bd = 0;
+                if (at < npair) {
+                    const unsigned e = pairs[at];
+                    const int slot = (int)(e >> 7) * 8 + sub;
+                    j = (int)(e & 127u);
+                    bd = sdesc[slot];
+                    const double *q = sph + 4 * slot;
+                    hit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
+                    my_tests += q[3] >= 0.0;
+                }
+                queue.push(hit, (long long)(lo + (bd >> 4)) << 4 | (long long)(bd & 15u), j, qoff);
+                if (queue.waiting() >= 64) drain();
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     while (queue.waiting() > 0) drain();
+    flush_counter(&ctr->samples, my_tests);
     flush_counter(&ctr->samples_binned, my_pairs);
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }

@@ -476,6 +476,37 @@ def merge_shards(img, cp, ctx, reduce='rccl'):
     return img
 
 
+def allreduce_small(values, cp, ctx, reduce='rccl'):
+    """Sum over the ranks of a float64 array that lives on the host (an image pair, S radiances):
+    reduce='rccl' -- ncclAllReduce through device scratch (nxc_allreduce_f64), with the
+    communicator created for the call; reduce='host' -- over the control plane (CPU tests,
+    diagnostics).  Integer-valued entries below 2^53 stay exact."""
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    if cp.world == 1:
+        return values
+    if reduce == 'rccl':
+        cp.init_rccl(ctx)
+        out = ctx.allreduce(values)
+        ctx.comm_destroy()
+        return out
+    if reduce == 'host':
+        return cp.allreduce(values)
+    raise ValueError("reduce must be 'rccl' or 'host'")
+
+
+def merge_catalogue(img, cp, ctx, reduce='rccl'):
+    """A ModelImage made from this rank's catalogue (finalize=False) becomes the image of the
+    whole shared run: image, packet counts and source total summed over the ranks
+    (ModelImage.py:96-98, where the reference sums over the files of one catalogue)."""
+    n = img.image.size
+    both = allreduce_small(np.concatenate([img.image.ravel(), img.packet_image.ravel(),
+                                           [img.totalsource]]), cp, ctx, reduce)
+    img.image = both[:n].reshape(img.image.shape).copy()
+    img.packet_image = both[n:2*n].reshape(img.packet_image.shape).copy()
+    img.totalsource = float(both[2*n])
+    return img
+
+
 def sharded_image(inputs, params, npackets, seed, cp=None, device=None, downcast=True,
                   sampler='device', packs_per_it=None, context=None, reduce='rccl'):
     """Multi-GPU ModelImage: every rank integrates and bins its contiguous shard of the global

@@ -6,10 +6,39 @@ GPU; the only thing replaced is the device: this class answers the handful of Co
 code calls, integrating and binning with oracle/c/oracle.c.  It lives under tests/ and is never
 imported by the package.
 """
+import weakref
+
 import numpy as np
 
 from oracle import np_oracle as O
 from oracle.c_oracle import COracle
+
+
+class OracleRowStore:
+    """Stand-in for hip_api.RowStore: the rows save() keeps, held on the host."""
+
+    def __init__(self, ctx, rows, index, narrow):
+        self.ctx, self._r, self.narrow = ctx, object(), narrow
+        self._rows, self._index = rows, index
+        self.total = rows.shape[1]
+        self.owners = weakref.WeakSet()
+
+    @property
+    def nbytes(self):
+        return self._rows.nbytes + self._index.nbytes
+
+    def download(self, first=0, count=None, index=True):
+        count = self.total - first if count is None else int(count)
+        return (self._rows[:, first:first + count].copy(),
+                self._index[first:first + count].copy() if index else None)
+
+    def free(self):
+        self._r = None
+
+    def spill(self):
+        for owner in list(self.owners):
+            owner._spill()
+        self.free()
 
 
 class OracleContext:
@@ -161,3 +190,74 @@ class OracleContext:
         self._last_ms = (time.perf_counter() - t0)*1e3
         self.calls.append((self.n_packets, self._first))
         return dict(traj=None, final=res['final'], steps=res['steps'])
+
+    # -- the two-stage flow: Input.run -> catalogue -> produce_image / LOSResult -----------------
+    _h = True                                # "alive", for ModelImage.context() / LOSResult.context()
+
+    def mem_info(self):
+        return 1 << 40, 1 << 40
+
+    def make_room(self, need):
+        pass
+
+    def integrate_const_rows(self, step, n_iter, outeredge, narrow=False, resident=False):
+        """The frac > 0 records of the dense trajectory, packet-major, with lossfrac in the
+        reference's association (Output.py:420-421) -- what nxc_integrate_const_rows delivers."""
+        X0 = np.ascontiguousarray(self._soa.T)
+        n, nrec = self.n_packets, n_iter + 1
+        res = self.co.integrate_const(self._forces, X0, step, n_iter, outeredge, nrec=nrec,
+                                      threads=self.threads)
+        traj = res['traj']                                   # (8, nrec, n)
+        frac = traj[7].T                                     # (n, nrec)
+        lossfrac = np.zeros_like(frac)
+        for ct in range(1, nrec):
+            act = frac[:, ct - 1] > 0
+            if not act.any():
+                break
+            lossfrac[act, ct] = (lossfrac[act, ct - 1] + frac[act, ct - 1]) - frac[act, ct]
+        live = frac > 0
+        rows = np.stack([traj[c].T[live] for c in range(8)] + [lossfrac[live]])
+        index = np.repeat(np.arange(n), live.sum(axis=1))
+        if narrow:
+            rows, index = rows.astype(np.float32), index.astype(np.int32)
+        self._ctr = dict(particle_steps=res['work'], samples=0, samples_binned=0, nonfinite=0,
+                         bad_step=0, neg_frac=0, unfinished=0)
+        self.calls.append((self.n_packets, self._first))
+        lengths = live.sum(axis=1).astype(np.int64)
+        if resident:
+            return dict(lengths=lengths, store=OracleRowStore(self, rows, index, narrow))
+        return dict(lengths=lengths, rows=rows)
+
+    def image_accumulate(self, x, y, z, vy, frac):
+        image, counts = self.co.image(self._desc, *(np.asarray(c, dtype=np.float64)
+                                                    for c in (x, y, z, vy, frac)))
+        self._image += image
+        self._counts += counts
+        self._ctr = dict(particle_steps=0, samples=len(x), samples_binned=int(counts.sum()),
+                         nonfinite=0, bad_step=0, neg_frac=0, unfinished=0)
+
+    def image_accumulate_rows(self, store, first=0, count=None):
+        rows, _ = store.download(first, count, index=False)
+        self.image_accumulate(rows[1], rows[2], rows[3], rows[5], rows[7])
+
+    def los_accumulate(self, dphi, sin_dphi, sin_2dphi, cos_threshold, vrplanet, unit_cm, g_tables,
+                       ladder, sc, x=None, y=None, z=None, vy=None, frac=None, index=None,
+                       n_index=0, used_cap=0, rows=None):
+        if rows is not None:
+            store, first, count, shift = rows
+            r, idx = store.download(first, count)
+            x, y, z, vy, frac, index = r[1], r[2], r[3], r[5], r[7], idx.astype(np.int64) - shift
+        smp = dict(x=np.asarray(x, float), y=np.asarray(y, float), z=np.asarray(z, float),
+                   vy=np.asarray(vy, float), frac=np.asarray(frac, float))
+        if index is not None:
+            smp['Index'] = np.asarray(index)
+        scd = dict(zip(('x', 'y', 'z', 'xbore', 'ybore', 'zbore'), np.asarray(sc)[:6]))
+        outeredge = float(np.max(np.asarray(sc)[6]))
+        radiance, npackets, included, used = O.los_iteration(
+            smp, scd, dphi, self.los_outeredge, vrplanet, list(g_tables), unit_cm,
+            n_index=n_index or None)
+        self._ctr = dict(particle_steps=0, samples=0, samples_binned=int(npackets.sum()),
+                         nonfinite=0, bad_step=0, neg_frac=0, unfinished=0)
+        return dict(radiance=radiance, npackets=npackets, included=included, used=None, n_used=0)
+
+    los_outeredge = 25.0

@@ -192,6 +192,86 @@ def test_a_failing_rank_ends_the_sharded_image_on_every_rank(tmp_path):
     assert any(v['peer'] and 'rank 5' in v['peer'] for r, v in enumerate(res) if r != 5)
 
 
+def _worker_two_stage(rank, world, port, tmpdir, kind):
+    """The reference's two-stage flow shared by `world` ranks: Input.run(cp=...) gives every rank
+    its Outputs of the single-process plan, produce_image(cp=...) and
+    LOSResult.simulate_data_from_inputs(cp=...) sum over the ranks what the reference sums over
+    the files.  Rank 0 also runs everything alone and compares."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    from nexoclom_amd import Input, LOSResult, SpacecraftData
+    from nexoclom_amd.distributed import ControlPlane, shard_range
+    from tests.oracle_context import OracleContext
+    cp = _plane(kind, world, rank)
+
+    def inputs_():
+        inputs = Input(INPUT)
+        inputs.options.endtime = type(inputs.options.endtime)(6000., 's')
+        return inputs
+    rng = np.random.default_rng(4)
+    th = np.linspace(0, 2*np.pi, 40, endpoint=False)
+    pos = np.stack([0.5*np.cos(th)*2, 2*np.sin(th)*0.6 - 0.4, 2*np.sin(th)*0.8], 1)
+    look = -pos + 0.6*rng.normal(size=pos.shape)
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
+    npackets, size, passes = 2300, 500, 5                 # 5 Outputs of 500: the last overshoots
+
+    def flow(cp_, ctx):
+        inputs = inputs_()
+        with contextlib.redirect_stdout(io.StringIO()):
+            inputs.run(npackets, packs_per_it=size, seed=77, context=ctx, cp=cp_)
+            image = inputs.produce_image(PARAMS, context=ctx, cp=cp_, reduce='host')
+            los = LOSResult(sc, inputs, dphi=np.radians(3.0), context=ctx)
+            los.simulate_data_from_inputs(sc, cp=cp_, reduce='host')
+        return inputs, image, los
+    ctx = OracleContext()
+    inputs, image, los = flow(cp, ctx)
+    lo, hi = shard_range(passes, rank, world)
+    assert len(inputs._catalogue) == hi - lo                       # only this rank's Outputs
+    assert [o.npackets for o in inputs._catalogue] == [size]*(hi - lo)
+    assert ctx.calls == [(size*(hi - lo), 0)]                      # ... integrated in one launch
+    assert los.npackets == size*passes and image.totalsource == los.totalsource
+    if rank == 0:
+        alone, image1, los1 = flow(None, OracleContext())
+        assert len(alone._catalogue) == passes
+        # Output k is the same Output whoever made it
+        for k, out in enumerate(inputs._catalogue):
+            same = alone._catalogue[lo + k]
+            assert np.array_equal(out.X0.values, same.X0.values)
+            assert np.array_equal(out.X.values, same.X.values)
+        assert image1.totalsource == image.totalsource == size*passes*201
+        assert image1.packet_image.sum() > 1000
+        assert np.array_equal(image.packet_image, image1.packet_image)
+        np.testing.assert_allclose(image.image, image1.image, rtol=1e-12, atol=0)
+        assert image.atoms_per_packet == image1.atoms_per_packet
+        assert los1.npackets_los.sum() > 100
+        assert np.array_equal(los.npackets_los.values, los1.npackets_los.values)
+        np.testing.assert_allclose(los.radiance.values, los1.radiance.values, rtol=1e-12, atol=0)
+        open(os.path.join(tmpdir, 'ok'), 'w').write('ok')
+    cp.barrier()
+    cp.close()
+
+
+@pytest.mark.parametrize('kind,world', [('tcp', 2), ('gloo', 2), ('tcp', 3)])
+def test_two_stage_flow_and_los_shared_by_ranks_equal_one_rank(tmp_path, kind, world):
+    port = 29300 + os.getpid() % 300 + 7*world + (11 if kind == 'gloo' else 0)
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker_two_stage, args=(r, world, port, str(tmp_path), kind))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert (tmp_path / 'ok').exists()
+
+
 def test_two_ranks_equal_one_rank_over_the_tcp_control_plane(tmp_path):
     _run('tcp', tmp_path)
 

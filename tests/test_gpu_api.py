@@ -253,6 +253,74 @@ def test_los_used_pairs_and_tiles(ctx):
     assert it['n_used'] == len(ref_pairs) and pairs == ref_pairs
 
 
+@pytest.mark.parametrize('layout', ['packets', 'no-index', 'scattered-index', 'tiny-packets'])
+def test_los_block_formation_follows_any_index_column(ctx, layout):
+    """k_los cuts the samples into blocks of at most 8 rows of ONE packet (the index column says
+    where packets end) and culls on the blocks' and groups' bounding spheres.  Whatever the
+    column looks like -- packets of 1..40 rows, packets of 1..3 rows, no column at all, ids in no
+    order (every row its own block) -- the pairs that are decided must be the reference's: counts,
+    `included` and the pair list exactly, radiance to 1e-10, against the KDTree restatement.  The
+    sample count is no multiple of anything, so ranges, blocks and groups end ragged."""
+    from nexoclom_amd.LOSResult import POSITION, BORESIGHT, arccos_threshold, los_geometry
+    import pandas as pd
+    rng = np.random.default_rng({'packets': 1, 'no-index': 2, 'scattered-index': 3,
+                                 'tiny-packets': 4}[layout])
+    f = H.mercury_forces('Na', 1.3)
+    top = 3 if layout == 'tiny-packets' else 40
+    lens = rng.integers(1, top + 1, 6000 if layout == 'tiny-packets' else 2500)
+    P = int(lens.sum()) - 3
+    ids = np.repeat(np.arange(len(lens)), lens)[:P]
+    # every packet a short straight flight from a random point near the planet
+    start = rng.normal(0, 1.5, (len(lens), 3))
+    vel = rng.normal(0, 0.04, (len(lens), 3))
+    k = np.arange(len(ids) + 3)[:P] - np.repeat(np.cumsum(lens) - lens, lens)[:P]
+    pts = start[ids] + vel[ids]*k[:, None]
+    vy = rng.normal(0, 2e-3, P)
+    frac = rng.uniform(0.05, 1, P)
+    if layout == 'scattered-index':
+        order = rng.permutation(P)
+        pts, vy, frac, ids = pts[order], vy[order], frac[order], ids[order]
+    pos, look = _orbit(200, seed=9)
+    dphi = np.radians(2.0)
+    spectra = pd.DataFrame(dict(zip(POSITION + BORESIGHT, list(pos.T) + list(look.T))))
+    cut, lengths, ladder = los_geometry(spectra, 25., dphi)
+    sc = np.vstack([pos.T, look.T, cut, lengths.astype(float)])
+    gt = H.g_tables('Na', f.aplanet, f.R_km, (5891, 5897))
+    setup = (dphi, np.sin(dphi), np.sin(2*dphi), arccos_threshold(dphi), f.vrplanet, f.R_km*1e5,
+             gt, ladder, sc)
+    cols = [np.ascontiguousarray(c) for c in (pts[:, 0], pts[:, 1], pts[:, 2], vy, frac)]
+    index = None if layout == 'no-index' else ids.astype(np.int64)
+    n_index = P if index is None else len(lens)
+    res = ctx.los_accumulate(*setup, *cols, index=index, n_index=n_index, used_cap=400000)
+    tests = ctx.counters()['samples']
+    smp = dict(x=cols[0], y=cols[1], z=cols[2], vy=vy, frac=frac,
+               Index=np.arange(P) if index is None else index)
+    scd = {c: spectra[c].values for c in spectra.columns}
+    r, n, inc, used = O.los_iteration(smp, scd, dphi, 25., f.vrplanet, gt, f.R_km*1e5,
+                                      n_index=n_index)
+    assert n.sum() > 300
+    assert np.array_equal(res['npackets'], n) and np.array_equal(res['included'], inc)
+    np.testing.assert_allclose(res['radiance'], r, rtol=1e-10, atol=0)
+    pairs = set(zip(res['used'][0].tolist(), res['used'][1].tolist()))
+    assert res['n_used'] == len(pairs) == sum(len(u) for u in used)
+    assert pairs == {(i, int(row)) for i, rows in enumerate(used) for row in rows}
+    # the culling culls: far fewer sphere tests than (block, spectrum) pairs -- except where every
+    # row is a block of its own
+    if layout in ('packets', 'no-index'):
+        assert tests < 0.6*((P + 7)//8)*200, tests
+    # a non-finite row goes to the exact test (which drops it like the reference), its neighbours
+    # are decided as before
+    cols[0][1000] = np.nan
+    cols[2][2000] = np.inf
+    res2 = ctx.los_accumulate(*setup, *cols, index=index, n_index=n_index)
+    ok = np.ones(P, bool); ok[[1000, 2000]] = False
+    smp2 = {k_: v[ok] for k_, v in smp.items()}
+    r2, n2, inc2, _ = O.los_iteration(smp2, scd, dphi, 25., f.vrplanet, gt, f.R_km*1e5,
+                                      n_index=n_index)
+    assert np.array_equal(res2['npackets'], n2)
+    np.testing.assert_allclose(res2['radiance'], r2, rtol=1e-10, atol=0)
+
+
 def test_device_sampler_matches_philox_oracle_and_reference_statistics(ctx):
     """f-4: k_sample == NumPy Philox restatement (to libm rounding), is counter-addressed
     (chunks concatenate), and is statistically the reference's source (KS tests in the spirit of

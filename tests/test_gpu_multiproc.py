@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, npackets, seed, sampler):
+def _launch(world, npackets, seed, sampler, flow='streaming'):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -33,7 +33,7 @@ def _launch(world, npackets, seed, sampler):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    TORCHELASTIC_RUN_ID=f'nxc-test-{port}')
         procs.append(subprocess.Popen([sys.executable, WORKER, str(npackets), str(seed), sampler,
-                                       'host'], env=env, stdout=subprocess.PIPE,
+                                       'host', flow], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     lines = []
     try:
@@ -65,3 +65,27 @@ def test_ranks_as_processes_give_the_one_rank_image(sampler):
             assert r['binned'] == single['binned'] and r['totalsource'] == single['totalsource']
             assert r['npackets'] == npackets
             assert abs(r['image_sum'] - single['image_sum']) <= 1e-10*abs(single['image_sum'])
+
+
+@pytest.mark.parametrize('sampler', ['numpy', 'pcg64'])
+def test_two_stage_flow_shared_by_processes_gives_the_one_process_result(sampler):
+    """Input.run(cp=...) + produce_image(cp=...) + LOSResult.simulate_data_from_inputs(cp=...) with
+    2 and 3 real processes on the GPU: every rank catalogues its share of the plan's Outputs (rows
+    resident in its own context) and every rank ends with the image and the line-of-sight
+    totals of the whole run -- packet counts per pixel and per spectrum identical to one process."""
+    npackets, seed = 14000, 9                      # 5 Outputs of 3000 (the last one overshoots)
+    single, = _launch(1, npackets, seed, sampler, 'two-stage')
+    assert single['outputs_here'] == 5 and single['npackets'] == 15000
+    assert single['binned'] > 1e5 and single['los_pairs'] > 100
+    for world in (2, 3):
+        ranks = _launch(world, npackets, seed, sampler, 'two-stage')
+        assert sum(r['outputs_here'] for r in ranks) == 5
+        assert sorted(r['outputs_here'] for r in ranks)[0] >= 1
+        for r in ranks:
+            assert r['counts_sha1'] == single['counts_sha1']
+            assert r['los_counts_sha1'] == single['los_counts_sha1']
+            assert r['binned'] == single['binned'] and r['totalsource'] == single['totalsource']
+            assert r['npackets'] == single['npackets'] and r['los_pairs'] == single['los_pairs']
+            assert abs(r['image_sum'] - single['image_sum']) <= 1e-10*abs(single['image_sum'])
+            assert abs(r['los_radiance_sum'] - single['los_radiance_sum']) <= \
+                1e-10*abs(single['los_radiance_sum'])

@@ -82,7 +82,9 @@ def main():
         store = res['store']
         P = store.total
         rows = store.download(index=False)[0]
-        store.free()
+        if _ < reps - 1:
+            store.free()
+    los_store = store                           # stays in HBM for the line-of-sight line below
     work = ctx.counters()["particle_steps"]
     line('k_const_fused<ROWS> one chunk', ms_rows, P, 'live records written', 72,
          f'{n} packets (ONE reference chunk: fewer packets than the chip has lanes, so the launch '
@@ -169,12 +171,21 @@ def main():
     args = (los.dphi, np.sin(los.dphi), np.sin(2*los.dphi), arccos_threshold(los.dphi),
             float(out.vrplanet), out.unit_km*1e5, los.g_tables(float(out.aplanet)), ladder, scarr,
             x, y, z, vy, frac)
-    for _ in range(reps):
-        r = ctx.los_accumulate(*args)
-        ms = ctx.last_kernel_ms()
-    line('k_los', ms, P*S, '(sample, spectrum) pair tests', 40.0/S,
-         f'{P} samples x {S} spectra, {int(r["npackets"].sum())} pairs inside cones; each sample '
-         f'(40 B) is read once per 128-spectrum tile')
+    # the resident rows with their packet-index column (what LOSResult hands over): blocks follow
+    # the packets; and the same samples as bare host columns (no index: blocks of 8 rows as they come)
+    for name, kw in (('k_los', dict(rows=(los_store, 0, los_store.total, 0), n_index=n)),
+                     ('k_los[host columns, no index]', dict(zip(('x', 'y', 'z', 'vy', 'frac'),
+                                                              (x, y, z, vy, frac))))):
+        for _ in range(reps):
+            r = ctx.los_accumulate(*args[:9], **kw)
+            ms = ctx.last_kernel_ms()
+        tests = ctx.counters()['samples']
+        line(name, ms, P*S, '(sample, spectrum) pairs decided', 40.0/S,
+             f'{P} samples x {S} spectra, {int(r["npackets"].sum())} pairs inside cones, '
+             f'{tests} bounding-sphere tests (groups of 8 blocks, then blocks of 8 rows: one test '
+             f'per {P*S/max(tests, 1):.0f} pairs; round 3 tested every (block, spectrum): '
+             f'{(P + 7)//8*S}); each sample (40 B) is read once per 128-spectrum tile')
+    los_store.free()
 
     # ---- bench-sized resident set: sampler, ordering, variable-step driver ---------------------
     N = 10_000_000
