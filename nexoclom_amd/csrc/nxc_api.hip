@@ -361,6 +361,8 @@ struct nxc_handle {
     size_t samples_cap = 0;
     unsigned char *d_tiles = nullptr;     // chunk scratch of the tiled image (k_image_bin -> k_image_tiles)
     size_t tiles_cap = 0;
+    unsigned char *d_losblk = nullptr;    // block descriptors + spheres (k_los_blocks -> k_los)
+    size_t losblk_cap = 0;
     int image_mode = 0;                   // nxc_image_mode: 0 by size, 1 k_image, 2 tiles
     int tile_pixels = NXC_TILE_PIXELS;
     int64_t tile_slab = int64_t(1) << 28; // samples per pass of the tiled image (bounds its scratch)
@@ -1066,24 +1068,49 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     if (P > 0) {
         if ((rc = prep_kernel(k_los<T, I>, lds))) return rc;
         const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
-        int gx = flat_grid(h, (P + NXC_LOS_BLOCK - 1) / NXC_LOS_BLOCK, NXC_LOS_THREADS);
-        if (tiles > 1) gx = std::max(1, gx / std::min(tiles, 8));
-        // every wave owns a contiguous range of rows (it follows the packets through them)
-        const int64_t n_waves = (int64_t)gx * (NXC_LOS_THREADS / 64);
-        const int64_t rows_per_wave = ((P + n_waves - 1) / n_waves + 63) / 64 * 64;
-        if (rows_per_wave >= (int64_t(1) << 27))
-            return fail(NXC_ERR_ARG, "too many samples for one line-of-sight call (2^27 per wave)");
+        constexpr int WPG = NXC_LOS_THREADS / 64;                  // waves per workgroup of k_los
+        // the samples go through in slabs: the block scratch is sized for the worst case of one
+        // slot per row (40 bytes; the bench cloud uses a fifth of a slot per row)
+        const int64_t slab = std::min<int64_t>(P, int64_t(1) << 24);
+        // (every region may add 7 empty slots to complete its last group)
+        const int64_t max_regions = (slab + NXC_LOS_FORM - 1) / NXC_LOS_FORM;
+        const size_t max_slots = (size_t)(slab + 8 * max_regions);
+        const size_t o_desc = 0, o_sph = (max_slots * 8 + 255) & ~size_t(255),
+                     o_n = o_sph + max_slots * 32, o_next = o_n + 256;
+        if ((rc = ensure(reinterpret_cast<void **>(&h->d_losblk), &h->losblk_cap,
+                         o_next + (size_t)tiles * 4)))
+            return rc;
+        unsigned long long *bdesc = reinterpret_cast<unsigned long long *>(h->d_losblk + o_desc);
+        double *bsph = reinterpret_cast<double *>(h->d_losblk + o_sph);
+        unsigned long long *n_slots = reinterpret_cast<unsigned long long *>(h->d_losblk + o_n);
+        unsigned *next_trip = reinterpret_cast<unsigned *>(h->d_losblk + o_next);
         if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL((k_los<T, I>), dim3(gx, tiles), dim3(NXC_LOS_THREADS), lds, st, K, base + o_blob,
-                           (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc), P,
-                           rows_per_wave, dx, dy, dz, dvy, dfrac, d_index,
-                           reinterpret_cast<const double *>(base + o_lad),
-                           reinterpret_cast<double *>(base + o_rad),
-                           reinterpret_cast<unsigned long long *>(base + o_np),
-                           included ? base + o_inc : nullptr, (long long)used_cap,
-                           used_pairs ? reinterpret_cast<long long *>(base + o_used) : nullptr,
-                           reinterpret_cast<unsigned long long *>(base + o_nu), h->d_ctr);
-        HIPCHK(hipGetLastError());
+        for (int64_t first = 0; first < P; first += slab) {
+            const int64_t n = std::min<int64_t>(slab, P - first);
+            const int64_t regions = (n + NXC_LOS_FORM - 1) / NXC_LOS_FORM;
+            K.row_base = first;
+            HIPCHK(hipMemsetAsync(n_slots, 0, 256 + (size_t)tiles * 4, st));      // + the trip counters
+            hipLaunchKernelGGL((k_los_blocks<T, I>),
+                               dim3((unsigned)((regions + NXC_BLOCK / 64 - 1) / (NXC_BLOCK / 64))),
+                               dim3(NXC_BLOCK), 0, st, n, K.cull, dx + first, dy + first, dz + first,
+                               d_index ? d_index + first : d_index, bdesc, bsph, n_slots);
+            HIPCHK(hipGetLastError());
+            // persistent waves, one workgroup per CU (its LDS holds all the spectra of a tile)
+            const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(h->n_cu, (n / 8 / 64 + WPG) / WPG));
+            hipLaunchKernelGGL((k_los<T, I>), dim3((unsigned)groups, tiles),
+                               dim3(NXC_LOS_THREADS), lds, st, K, base + o_blob,
+                               (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc),
+                               n_slots, bdesc, bsph, next_trip, dx + first, dy + first,
+                               dz + first, dvy + first, dfrac + first,
+                               d_index ? d_index + first : d_index,
+                               reinterpret_cast<const double *>(base + o_lad),
+                               reinterpret_cast<double *>(base + o_rad),
+                               reinterpret_cast<unsigned long long *>(base + o_np),
+                               included ? base + o_inc : nullptr, (long long)used_cap,
+                               used_pairs ? reinterpret_cast<long long *>(base + o_used) : nullptr,
+                               reinterpret_cast<unsigned long long *>(base + o_nu), h->d_ctr);
+            HIPCHK(hipGetLastError());
+        }
         if ((rc = end_timed(h))) return rc;
     }
     HIPCHK(hipMemcpyAsync(radiance, base + o_rad, (size_t)S * 8, hipMemcpyDeviceToHost, st));
@@ -1382,7 +1409,7 @@ int nxc_destroy(nxc_handle *h)
     void *ptrs[] = {h->d_blob, h->d_image, h->d_packets, h->d_ctr, h->d_scratch,
                     h->d_steps, h->d_reduce, h->d_order, h->d_bounce, h->d_moonpos, h->d_offsets,
                     h->d_source, h->d_queue, h->d_samples, h->d_tiles, h->d_hist, h->d_rec, h->d_piece_hist,
-                    h->d_blob_img, h->d_reduce_n};
+                    h->d_blob_img, h->d_reduce_n, h->d_losblk};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     pool_flush(h);

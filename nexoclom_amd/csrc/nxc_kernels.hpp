@@ -1147,11 +1147,12 @@ struct LosK {
     int cull, pad_;                // 1: every boresight is a unit vector (checked on the host)
     int n_lines, n_ladder;
     int64_t index_shift;           // subtracted from the index column: packet number inside its Output
+    int64_t row_base;              // row number of the first sample of this launch (slabs)
     int64_t tile_off;              // byte offset of the spectra tile inside the LDS block
     LutDesc line[4];
 };
 
-constexpr int NXC_LOS_TILE = 128;  // spectra per workgroup tile (8 doubles each)
+constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile, all of them in LDS (8 doubles each)
 #ifndef NXC_LOS_BLOCK_N             // (overridable: tools/ experiments)
 #define NXC_LOS_BLOCK_N 8
 #endif
@@ -1211,12 +1212,12 @@ NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spec
     if (wtemp != 0.0) unsafeAtomicAdd(&radiance[spectrum], wtemp);
     atomicAdd(&npackets[spectrum], 1ull);
     my_pairs++;
-    if (included) included[index ? (long long)index[p] - K.index_shift : p] = 1;
+    if (included) included[index ? (long long)index[p] - K.index_shift : p + K.row_base] = 1;
     if (used_pairs && wtemp > 0.0) {
         const unsigned long long slot = atomicAdd(n_used, 1ull);
         if ((long long)slot < used_cap) {
             used_pairs[slot] = spectrum;
-            used_pairs[used_cap + slot] = p;
+            used_pairs[used_cap + slot] = p + K.row_base;
         }
     }
 }
@@ -1309,7 +1310,8 @@ NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy
 // T: double, or float for samples as Output.save() stores them (widened exactly, like restore());
 // I: the type of the packet-index column (int64, or int32 as save() stores it).
 //
-// Two levels of culling in front of the exact pair test, both on bounding spheres.
+// Two levels of culling in front of the exact pair test, both on bounding spheres, prepared by a
+// pass of its own over the samples (k_los_blocks) and used by k_los for every spectrum.
 //
 // BLOCKS.  The rows of an Output are packet-major (Output.py:435-449), so consecutive rows are
 // consecutive steps of one packet -- until the packet ends.  A block is at most NXC_LOS_BLOCK
@@ -1317,38 +1319,211 @@ NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy
 // trajectory, a small sphere.  (Blocks cut from the row numbers alone straddle packet ends -- one
 // block in six for the bench cloud -- and such a block is as large as the distance between the two
 // packets: 2.5 % of all (block, cone) tests passed, against 0.15 % for blocks that respect the
-// packets.)  A wave owns a contiguous range of rows; it reads the index column 256 rows at a time,
-// finds the packet starts with a prefix maximum across its lanes, and files the block descriptors
-// ((row - range start) << 4 | rows) in a ring in LDS from which it takes 64 at a time: every lane
-// holds a block whatever the packet lengths.  Without an index column the rows are one packet.
+// packets.)  Without an index column the rows are one packet.
 //
-// GROUPS.  The 8 blocks held by 8 adjacent lanes (up to 64 rows, mostly one packet) form a group
-// with a bounding sphere of its own.  The 8 lanes share the group's cone tests -- lane i tests the
-// spectra i, i + 8, ... of the tile: 16 tests per lane instead of 128 -- and only the (group,
-// spectrum) pairs that pass (7 % for the bench cloud) are looked at block by block: 8 pairs per
-// wave instruction, one lane per (pair, block).  Sphere tests per 8 rows: 128 per tile before,
-// about 16 + 9 now.  What passes the block test -- one (block, spectrum) pair in 700 -- goes through
-// the per-wave LDS queue, so that its rows meet los_pair with full waves.
+// GROUPS.  Eight consecutive block SLOTS form a group with a bounding sphere of its own, and a
+// packet of two blocks or more starts on a fresh group (the slots skipped stay empty: 16 % of
+// them for the bench cloud), so that a group is a piece of ONE trajectory as well: 10 % of the
+// (group, cone) tests pass, 25 % when groups are cut from the block numbers alone.
+//
+// k_los_blocks: a wave owns a contiguous range of rows; it reads the index column 256 rows at a
+// time, finds the packet starts with a prefix maximum across its lanes, places the blocks with a
+// prefix scan that knows about the fresh-group rule, and writes {first row << 4 | rows} and the
+// bounding sphere of every slot to its region of the scratch arrays (at most one slot per row).
+// k_los: the same wave takes its region 64 slots at a time, one block per lane.  The 8 lanes of a
+// group share the group's cone tests -- lane i tests the spectra i, i + 8, ... -- and only the
+// (group, spectrum) pairs that pass are looked at block by block: 8 pairs per wave instruction,
+// one lane per (pair, block).  Sphere tests per block and spectrum: one before, a quarter now.
+// What passes the block test -- one (block, spectrum) pair in 700 -- goes through the per-wave LDS
+// queue, so that its rows meet los_pair with full waves.  All the spectra of a launch (up to
+// NXC_LOS_TILE = 512) sit in LDS, so blocks and spheres are read once for all of them.
 // K.cull = 0 (boresights that are not unit vectors) gives every block an infinite radius.
-constexpr int NXC_LOS_RING = 512;        // block descriptors waiting per wave (< 64 + 256 new)
 constexpr int NXC_LOS_FORM = 256;        // rows whose packet ids are examined at a time: 4 per lane
+
+// The placement scan.  A lane's blocks move the write position like pos -> pos + a (no fresh
+// group among them) or pos -> roundup8(pos + a) + c (a blocks, then a fresh group, then c more
+// slots with the later round-ups resolved: they start from a multiple of 8).  Composition is
+// associative, so the positions of all lanes come out of six shuffle steps.
+struct LosPlace {
+    int fresh, a, c;
+};
+NXC_DEV LosPlace los_place_then(const LosPlace &f, const LosPlace &g)   // first f, then g
+{
+    if (!f.fresh) return LosPlace{g.fresh, f.a + g.a, g.c};
+    if (!g.fresh) return LosPlace{1, f.a, f.c + g.a};
+    return LosPlace{1, f.a, ((f.c + g.a + 7) & ~7) + g.c};
+}
+NXC_DEV long long los_place_apply(const LosPlace &f, long long pos)
+{
+    return f.fresh ? ((pos + f.a + 7) & ~7ll) + f.c : pos + f.a;
+}
+
+// One wave per REGION of NXC_LOS_FORM rows: packet starts from the index column, blocks, placement,
+// spheres -- everything from one round of loads of the ids and one of the coordinates.  A region
+// starts a packet of its own (a packet cut by a region's edge continues as another "packet" in the
+// next region: one block in thirty more than strictly needed).  The region's slots -- a whole
+// number of groups -- go to the next free place of ONE stream of slots (a returning atomic per
+// region; the order of the regions in the stream does not matter), so that k_los reads dense trips.
+template <typename T, typename I>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__ y,
+             const T *__restrict__ z, const I *__restrict__ index,
+             unsigned long long *__restrict__ bdesc, double *__restrict__ bsph,
+             unsigned long long *__restrict__ n_slots)
+{
+    static_assert(NXC_LOS_BLOCK == 8, "groups of 8 slots of 8 rows");
+    const int lane = threadIdx.x & 63;
+    const int64_t region = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t lo = region * NXC_LOS_FORM;
+    if (lo >= P) return;
+    const int64_t hi = lo + NXC_LOS_FORM < P ? lo + NXC_LOS_FORM : P;
+    long long stream0 = 0;             // where this region's slots start in the stream
+    auto put = [&](int slot, unsigned long long desc, double cx, double cy, double cz, double R) {
+        bdesc[stream0 + slot] = desc;
+        nxc_v2d *q = reinterpret_cast<nxc_v2d *>(bsph + 4 * (stream0 + slot));
+        nxc_v2d u, v;
+        u.x = cx; u.y = cy; v.x = cz; v.y = R;
+        q[0] = u; q[1] = v;
+    };
+    const int64_t r0 = lo + 4 * lane;
+    long long id[4] = {0, 0, 0, 0};
+    long long prev = 0;
+    if (index) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (r0 + k < hi) id[k] = (long long)index[r0 + k];
+        if (lane > 0 && r0 < hi) prev = (long long)index[r0 - 1];
+    }
+    // positions inside the region: rel = 4 lane + k; a row past the end counts as a packet start
+    bool bnd[4];
+    int last = -1, first = NXC_LOS_FORM;       // my last / first packet start (none: -1 / beyond)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rel = 4 * lane + k;
+        bnd[k] = r0 + k >= hi || rel == 0 || (index && id[k] != (k ? id[k - 1] : prev));
+        if (bnd[k]) last = rel;
+    }
+#pragma unroll
+    for (int k = 3; k >= 0; k--)
+        if (bnd[k]) first = 4 * lane + k;
+    int unused;
+    const int before = wave_excl_max(last, unused);          // last start in the lanes below mine
+    // first start in the lanes above mine: a suffix minimum
+    int after = first;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_down(after, off, 64);
+        if (lane + off < 64) after = after < o ? after : o;
+    }
+    after = __shfl_down(after, 1, 64);
+    if (lane == 63) after = NXC_LOS_FORM;
+    int start = before;                        // start of the packet of the row before mine
+    unsigned long long d[4] = {0, 0, 0, 0};
+    bool emit[4], fresh[4];
+    LosPlace mine{0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rel = 4 * lane + k;
+        if (bnd[k]) start = rel;
+        emit[k] = r0 + k < hi && ((rel - start) & (NXC_LOS_BLOCK - 1)) == 0;
+        fresh[k] = false;
+        if (emit[k]) {
+            int nextb = after;                 // the next packet start after this row
+#pragma unroll
+            for (int m = 3; m > 0; m--)
+                if (m > k && bnd[m]) nextb = 4 * lane + m;
+            const int run = nextb - rel;       // rows of this packet from here on (the region's end is a start)
+            const int n = run < NXC_LOS_BLOCK ? run : NXC_LOS_BLOCK;
+            d[k] = (unsigned long long)(r0 + k) << 4 | (unsigned long long)n;
+            fresh[k] = rel == start && run > NXC_LOS_BLOCK;  // a packet of two blocks or more opens a group
+            mine = los_place_then(mine, fresh[k] ? LosPlace{1, 0, 1} : LosPlace{0, 1, 0});
+        }
+    }
+    LosPlace incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        LosPlace o;
+        o.fresh = __shfl_up(incl.fresh, off, 64);
+        o.a = __shfl_up(incl.a, off, 64);
+        o.c = __shfl_up(incl.c, off, 64);
+        if (lane >= off) incl = los_place_then(o, incl);
+    }
+    LosPlace all, excl;
+    all.fresh = __builtin_amdgcn_readlane(incl.fresh, 63);
+    all.a = __builtin_amdgcn_readlane(incl.a, 63);
+    all.c = __builtin_amdgcn_readlane(incl.c, 63);
+    excl.fresh = __shfl_up(incl.fresh, 1, 64);
+    excl.a = __shfl_up(incl.a, 1, 64);
+    excl.c = __shfl_up(incl.c, 1, 64);
+    int pos = lane == 0 ? 0 : (int)los_place_apply(excl, 0);
+    // the last group is completed with empty slots
+    const int tail = (int)los_place_apply(all, 0);
+    const int full = (tail + 7) & ~7;
+    unsigned long long got = 0;
+    if (lane == 0) got = atomicAdd(n_slots, (unsigned long long)full);
+    stream0 = wave_bcast0((long long)got);
+    if (tail + lane < full) put(tail + lane, 0ull, 0.0, 0.0, 0.0, -1.0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!emit[k]) continue;
+        if (fresh[k]) {
+            const int up = (pos + 7) & ~7;
+            for (; pos < up; pos++) put(pos, 0ull, 0.0, 0.0, 0.0, -1.0);         // slots left empty
+        }
+        const int64_t p0 = (int64_t)(d[k] >> 4);
+        const int nb = (int)(d[k] & 15ull);
+        // bounding sphere: centre of the bounding box, largest distance from it
+        double px[NXC_LOS_BLOCK], py[NXC_LOS_BLOCK], pz[NXC_LOS_BLOCK];
+#pragma unroll
+        for (int s_ = 0; s_ < NXC_LOS_BLOCK; s_++) {
+            const int64_t p = p0 + (s_ < nb ? s_ : 0);       // all the loads in flight together
+            px[s_] = (double)x[p]; py[s_] = (double)y[p]; pz[s_] = (double)z[p];
+        }
+        double lox = px[0], hix = lox, loy = py[0], hiy = loy, loz = pz[0], hiz = loz;
+#pragma unroll
+        for (int s_ = 1; s_ < NXC_LOS_BLOCK; s_++) {
+            lox = __builtin_fmin(lox, px[s_]); hix = __builtin_fmax(hix, px[s_]);
+            loy = __builtin_fmin(loy, py[s_]); hiy = __builtin_fmax(hiy, py[s_]);
+            loz = __builtin_fmin(loz, pz[s_]); hiz = __builtin_fmax(hiz, pz[s_]);
+        }
+        double cx = 0.5 * (lox + hix), cy = 0.5 * (loy + hiy), cz = 0.5 * (loz + hiz);
+        double R2 = 0.0;
+        bool nan_seen = false;
+#pragma unroll
+        for (int s_ = 0; s_ < NXC_LOS_BLOCK; s_++) {
+            const double ex = px[s_] - cx, ey = py[s_] - cy, ez = pz[s_] - cz;
+            const double e2 = (ex * ex + ey * ey) + ez * ez;
+            nan_seen = nan_seen || e2 != e2;   // (fmin / fmax drop a NaN: the box alone would not show it)
+            R2 = __builtin_fmax(R2, e2);
+        }
+        // a non-finite coordinate must reach los_pair (it decides such samples like the reference)
+        const bool finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
+        double R = __builtin_sqrt(R2) * (1.0 + 1e-12);
+        if (!finite || !cull) { cx = cy = cz = 0.0; R = __builtin_inf(); }
+        put(pos, d[k], cx, cy, cz, R);
+        pos++;
+    }
+}
+
 constexpr int NXC_LOS_PAIRS = 512;       // (group, spectrum) survivors of 8 tests per lane
-constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32 + 64 * 4 + NXC_LOS_PAIRS * 2;
+constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + 64 * 32 + 64 * 8 + NXC_LOS_PAIRS * 2;
 #ifndef NXC_LOS_THREADS
-#define NXC_LOS_THREADS 512
+#define NXC_LOS_THREADS 1024
 #endif
 template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_LOS_THREADS)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
-      const double *__restrict__ sc, int64_t P, int64_t rows_per_wave, const T *__restrict__ x,
-      const T *__restrict__ y, const T *__restrict__ z, const T *__restrict__ vy,
-      const T *__restrict__ frac, const I *__restrict__ index,
+      const double *__restrict__ sc, const unsigned long long *__restrict__ n_slots,
+      const unsigned long long *__restrict__ bdesc, const double *__restrict__ bsph,
+      unsigned *__restrict__ next_trip,
+      const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z,
+      const T *__restrict__ vy, const T *__restrict__ frac, const I *__restrict__ index,
       const double *__restrict__ ladder, double *__restrict__ radiance,
       unsigned long long *__restrict__ npackets, unsigned char *__restrict__ included,
       long long used_cap, long long *__restrict__ used_pairs,
       unsigned long long *__restrict__ n_used, DevCounters *__restrict__ ctr)
 {
-    static_assert(NXC_LOS_BLOCK <= 15, "a block descriptor keeps its row count in four bits");
+    static_assert(NXC_LOS_TILE <= 512, "a (group, spectrum) pair is 3 + 9 bits");
     stage_tables(blob, stage_bytes);
     const int64_t s0 = (int64_t)blockIdx.y * NXC_LOS_TILE;
     const int ns = (int)((S - s0) < NXC_LOS_TILE ? (S - s0) : NXC_LOS_TILE);
@@ -1362,15 +1537,12 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     unsigned long long my_pairs = 0, my_nonfinite = 0, my_tests = 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + wid * NXC_LOS_WAVE_BYTES;
-    unsigned *const ring = reinterpret_cast<unsigned *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
-    double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4);
-    unsigned *const sdesc = reinterpret_cast<unsigned *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32);
+    double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
+    unsigned long long *const sdesc =
+        reinterpret_cast<unsigned long long *>(nxc_lds + qoff + NXC_LOSQ_BYTES + 64 * 32);
     unsigned short *const pairs =
-        reinterpret_cast<unsigned short *>(nxc_lds + qoff + NXC_LOSQ_BYTES + NXC_LOS_RING * 4 + 64 * 32 + 64 * 4);
-    // this wave's rows
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wid;
-    const int64_t lo = wave * rows_per_wave < P ? wave * rows_per_wave : P;
-    const int64_t hi = lo + rows_per_wave < P ? lo + rows_per_wave : P;
+        reinterpret_cast<unsigned short *>(nxc_lds + qoff + NXC_LOSQ_BYTES + 64 * 32 + 64 * 8);
+    const long long count = (long long)*n_slots;              // a multiple of 8
     LosQueue queue;
     auto drain = [&]() {               // up to 64 queued candidates, one per lane
         long long qb = 0;
@@ -1386,93 +1558,26 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             }
         }
     };
-    int64_t next = lo;                 // first row whose packet id has not been looked at
-    int64_t carry = lo;                // where the packet that row `next - 1` belongs to starts
-    int rhead = 0, rtail = 0;          // the descriptor ring (wave-uniform)
+    const int grp = lane >> 3, sub = lane & 7;
+    // a trip: 64 consecutive slots of the stream, one per lane.  The trips differ in how much of
+    // them lies near a line of sight: a wave takes the next one when it is done with its own (one
+    // counter per tile of spectra)
     for (;;) {
-        // ---- block descriptors: until 64 are waiting or the range is used up ---------------------
-        while (rtail - rhead < 64 && next < hi) {
-            const int64_t r0 = next + 4 * lane;
-            long long id[4] = {0, 0, 0, 0};
-            bool bnd[4];
-            long long prev = 0;
-            if (index) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (r0 + k < hi) id[k] = (long long)index[r0 + k];
-                if (r0 > lo && r0 < hi) prev = (long long)index[r0 - 1];
-            }
-            int last = -1;             // last packet start among my rows, relative to `next`
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                bnd[k] = r0 + k < hi && (r0 + k == lo || (index && id[k] != (k ? id[k - 1] : prev)));
-                if (bnd[k]) last = 4 * lane + k;
-            }
-            int wave_last;
-            const int before = wave_excl_max(last, wave_last);
-            int64_t start = before >= 0 ? next + before : carry;   // start of the packet of row r0 - 1
-            unsigned d[4] = {0, 0, 0, 0};
-            bool emit[4];
-            int cnt = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int64_t r = r0 + k;
-                if (bnd[k]) start = r;
-                emit[k] = r < hi && ((r - start) & (NXC_LOS_BLOCK - 1)) == 0;
-                if (emit[k]) {
-                    int n = 1;         // rows of this block: same packet, inside the range
-                    while (n < NXC_LOS_BLOCK && r + n < hi &&
-                           (!index || (long long)index[r + n] == id[k]))
-                        n++;
-                    d[k] = (unsigned)(r - lo) << 4 | (unsigned)n;
-                    cnt++;
-                }
-            }
-            int total;
-            int at = rtail + wave_excl_sum(cnt, total);
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (emit[k]) ring[at++ & (NXC_LOS_RING - 1)] = d[k];
-            rtail += total;
-            if (wave_last >= 0) carry = next + wave_last;
-            next += NXC_LOS_FORM;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (rtail == rhead) break;
-        // ---- one trip: 64 blocks (fewer at the end of the range), one per lane ------------------
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int m = rtail - rhead < 64 ? rtail - rhead : 64;
-        const bool has = lane < m;
-        unsigned desc = 0;
+        unsigned trip = 0;
+        if (lane == 0) trip = atomicAdd(next_trip + blockIdx.y, 1u);
+        trip = (unsigned)__builtin_amdgcn_readfirstlane((int)trip);
+        const long long base = 64ll * trip;
+        if (base >= count) break;
+        const bool in = base + lane < count;
+        unsigned long long desc = 0;
         double cx = 0, cy = 0, cz = 0, R = -1.0;
-        if (has) {
-            desc = ring[(rhead + lane) & (NXC_LOS_RING - 1)];
-            const int64_t p0 = lo + (desc >> 4);
-            const int nb = (int)(desc & 15u);
-            // bounding sphere: centre of the bounding box, largest distance from it
-            double lox = (double)x[p0], hix = lox, loy = (double)y[p0], hiy = loy, loz = (double)z[p0], hiz = loz;
-            for (int s_ = 1; s_ < nb; s_++) {
-                const double vx_ = (double)x[p0 + s_], vy_ = (double)y[p0 + s_], vz_ = (double)z[p0 + s_];
-                lox = __builtin_fmin(lox, vx_); hix = __builtin_fmax(hix, vx_);
-                loy = __builtin_fmin(loy, vy_); hiy = __builtin_fmax(hiy, vy_);
-                loz = __builtin_fmin(loz, vz_); hiz = __builtin_fmax(hiz, vz_);
-            }
-            cx = 0.5 * (lox + hix); cy = 0.5 * (loy + hiy); cz = 0.5 * (loz + hiz);
-            double R2 = 0.0;
-            bool nan_seen = false;
-            for (int s_ = 0; s_ < nb; s_++) {
-                const double ex = (double)x[p0 + s_] - cx, ey = (double)y[p0 + s_] - cy, ez = (double)z[p0 + s_] - cz;
-                const double e2 = (ex * ex + ey * ey) + ez * ez;
-                nan_seen = nan_seen || e2 != e2;
-                R2 = __builtin_fmax(R2, e2);
-            }
-            // a non-finite coordinate must reach los_pair (it decides such samples like the reference)
-            const bool finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
-            if (finite && K.cull) R = __builtin_sqrt(R2) * (1.0 + 1e-12);
-            else { cx = cy = cz = 0.0; R = __builtin_inf(); }
+        if (in) {
+            desc = bdesc[base + lane];
+            const nxc_v2d *q = reinterpret_cast<const nxc_v2d *>(bsph + 4 * (base + lane));
+            const nxc_v2d u = q[0], v = q[1];
+            cx = u.x; cy = u.y; cz = v.x; R = v.y;
         }
-        rhead += m;
+        const bool has = R >= 0.0;
         sph[4 * lane] = cx; sph[4 * lane + 1] = cy; sph[4 * lane + 2] = cz; sph[4 * lane + 3] = R;
         sdesc[lane] = desc;
         // the group's sphere: centre of the box of its blocks' centres, radius to the farthest
@@ -1494,39 +1599,55 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
         }
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) GR = __builtin_fmax(GR, __shfl_xor(GR, off, 64));
+        // the eight group spheres as wave-uniform values (scalar registers)
+        double Gx[8], Gy[8], Gz[8], Gr[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            Gx[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gx_), 8 * g),
+                                     __builtin_amdgcn_readlane(__double2loint(gx_), 8 * g));
+            Gy[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gy_), 8 * g),
+                                     __builtin_amdgcn_readlane(__double2loint(gy_), 8 * g));
+            Gz[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gz_), 8 * g),
+                                     __builtin_amdgcn_readlane(__double2loint(gz_), 8 * g));
+            Gr[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(GR), 8 * g),
+                                     __builtin_amdgcn_readlane(__double2loint(GR), 8 * g));
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- group tests (8 spectra per lane and half), then their survivors block by block ------
-        const int grp = lane >> 3, sub = lane & 7;
-        for (int half = 0; half < 2; half++) {
+        // ---- group tests, 64 spectra at a time: a lane holds ONE spectrum (read from LDS once)
+        //      and meets the eight group spheres; then the survivors block by block ------------
+        for (int c0 = 0; c0 < ns; c0 += 64) {
+            const int jm = c0 + lane;
+            double spj[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) spj[c] = tile[(jm < ns ? jm : 0) * 8 + c];
             int npair = 0;
 #pragma unroll
-            for (int t = 0; t < NXC_LOS_TILE / 16; t++) {
-                const int j = sub + 8 * (t + half * (NXC_LOS_TILE / 16));
-                const bool hit = j < ns && los_sphere_hits(tile + j * 8, gx_, gy_, gz_, GR, K.tan_dphi);
-                my_tests += j < ns && GR >= 0.0;
+            for (int g = 0; g < 8; g++) {
+                const bool hit = jm < ns && los_sphere_hits(spj, Gx[g], Gy[g], Gz[g], Gr[g], K.tan_dphi);
+                my_tests += jm < ns && Gr[g] >= 0.0;
                 const unsigned long long mask = __ballot(hit);
-                if (hit) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(grp << 7 | j);
+                if (hit) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(g << 9 | jm);
                 npair += __popcll(mask);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int base = 0; base < npair; base += 8) {
-                const int at = base + grp;                    // eight pairs per wave instruction
+            for (int at0 = 0; at0 < npair; at0 += 8) {
+                const int at = at0 + grp;                     // eight pairs per wave instruction
                 bool hit = false;
                 int j = 0;
-                unsigned bd = 0;
+                unsigned long long bd = 0;
                 if (at < npair) {
                     const unsigned e = pairs[at];
-                    const int slot = (int)(e >> 7) * 8 + sub;
-                    j = (int)(e & 127u);
+                    const int slot = (int)(e >> 9) * 8 + sub;
+                    j = (int)(e & 511u);
                     bd = sdesc[slot];
                     const double *q = sph + 4 * slot;
                     hit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
                     my_tests += q[3] >= 0.0;
                 }
-                queue.push(hit, (long long)(lo + (bd >> 4)) << 4 | (long long)(bd & 15u), j, qoff);
+                queue.push(hit, (long long)bd, j, qoff);
                 if (queue.waiting() >= 64) drain();
             }
             __builtin_amdgcn_wave_barrier();

@@ -304,10 +304,11 @@ def test_los_block_formation_follows_any_index_column(ctx, layout):
     pairs = set(zip(res['used'][0].tolist(), res['used'][1].tolist()))
     assert res['n_used'] == len(pairs) == sum(len(u) for u in used)
     assert pairs == {(i, int(row)) for i, rows in enumerate(used) for row in rows}
-    # the culling culls: far fewer sphere tests than (block, spectrum) pairs -- except where every
-    # row is a block of its own
-    if layout in ('packets', 'no-index'):
-        assert tests < 0.6*((P + 7)//8)*200, tests
+    # the culling culls: fewer sphere tests than (block, spectrum) pairs even for this compact
+    # cloud seen from close by (the bench cloud: a quarter) -- except where every row is a block
+    # of its own
+    if layout == 'packets':
+        assert tests < 0.8*((P + 7)//8)*200, tests
     # a non-finite row goes to the exact test (which drops it like the reference), its neighbours
     # are decided as before
     cols[0][1000] = np.nan
