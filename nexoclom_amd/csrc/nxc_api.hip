@@ -1091,8 +1091,9 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
             K.row_base = first;
             HIPCHK(hipMemsetAsync(n_slots, 0, 256 + (size_t)tiles * 4, st));      // + the trip counters
             hipLaunchKernelGGL((k_los_blocks<T, I>),
-                               dim3((unsigned)((regions + NXC_BLOCK / 64 - 1) / (NXC_BLOCK / 64))),
-                               dim3(NXC_BLOCK), 0, st, n, K.cull, dx + first, dy + first, dz + first,
+                               dim3((unsigned)((regions + NXC_LOS_BLOCKS_THREADS / 64 - 1) /
+                                               (NXC_LOS_BLOCKS_THREADS / 64))),
+                               dim3(NXC_LOS_BLOCKS_THREADS), 0, st, n, K.cull, dx + first, dy + first, dz + first,
                                d_index ? d_index + first : d_index, bdesc, bsph, n_slots);
             HIPCHK(hipGetLastError());
             // persistent waves, one workgroup per CU (its LDS holds all the spectra of a tile)

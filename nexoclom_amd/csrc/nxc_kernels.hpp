@@ -1364,8 +1364,9 @@ NXC_DEV long long los_place_apply(const LosPlace &f, long long pos)
 // next region: one block in thirty more than strictly needed).  The region's slots -- a whole
 // number of groups -- go to the next free place of ONE stream of slots (a returning atomic per
 // region; the order of the regions in the stream does not matter), so that k_los reads dense trips.
+constexpr int NXC_LOS_BLOCKS_THREADS = 1024;     // 16 regions per workgroup, one atomic for all of them
 template <typename T, typename I>
-__global__ void __launch_bounds__(NXC_BLOCK)
+__global__ void __launch_bounds__(NXC_LOS_BLOCKS_THREADS)
 k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__ y,
              const T *__restrict__ z, const I *__restrict__ index,
              unsigned long long *__restrict__ bdesc, double *__restrict__ bsph,
@@ -1374,8 +1375,7 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
     static_assert(NXC_LOS_BLOCK == 8, "groups of 8 slots of 8 rows");
     const int lane = threadIdx.x & 63;
     const int64_t region = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t lo = region * NXC_LOS_FORM;
-    if (lo >= P) return;
+    const int64_t lo = region * NXC_LOS_FORM < P ? region * NXC_LOS_FORM : P;       // (past the end: empty)
     const int64_t hi = lo + NXC_LOS_FORM < P ? lo + NXC_LOS_FORM : P;
     long long stream0 = 0;             // where this region's slots start in the stream
     auto put = [&](int slot, unsigned long long desc, double cx, double cy, double cz, double R) {
@@ -1459,9 +1459,19 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
     // the last group is completed with empty slots
     const int tail = (int)los_place_apply(all, 0);
     const int full = (tail + 7) & ~7;
-    unsigned long long got = 0;
-    if (lane == 0) got = atomicAdd(n_slots, (unsigned long long)full);
-    stream0 = wave_bcast0((long long)got);
+    // one returning atomic per WORKGROUP (a single address takes about 80 million a second: one
+    // per region would cost half a millisecond for 1e7 rows)
+    __shared__ long long wg_base[NXC_LOS_BLOCKS_THREADS / 64 + 1];
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) wg_base[wid + 1] = full;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long sum = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { const long long c = wg_base[w + 1]; wg_base[w + 1] = sum; sum += c; }
+        wg_base[0] = (long long)atomicAdd(n_slots, (unsigned long long)sum);
+    }
+    __syncthreads();
+    stream0 = wg_base[0] + wg_base[wid + 1];
     if (tail + lane < full) put(tail + lane, 0ull, 0.0, 0.0, 0.0, -1.0);
 #pragma unroll
     for (int k = 0; k < 4; k++) {

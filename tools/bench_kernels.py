@@ -184,7 +184,8 @@ def main():
              f'{P} samples x {S} spectra, {int(r["npackets"].sum())} pairs inside cones, '
              f'{tests} bounding-sphere tests (groups of 8 blocks, then blocks of 8 rows: one test '
              f'per {P*S/max(tests, 1):.0f} pairs; round 3 tested every (block, spectrum): '
-             f'{(P + 7)//8*S}); each sample (40 B) is read once per 128-spectrum tile')
+             f'{(P + 7)//8*S}); the samples are read once by k_los_blocks (16 B) and again only where a '
+             f'block passes a cone')
     los_store.free()
 
     # ---- bench-sized resident set: sampler, ordering, variable-step driver ---------------------
