@@ -206,6 +206,10 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
 
 /* ---- resident packets / image (what a long run keeps in HBM) ----------------------------------- */
 int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0);
+/* The same for a resident set that the host holds in pieces (the Outputs of one launch of
+ * Input.run, each an [8][counts[p]] array): piece p's packets follow those of the pieces before it. */
+int nxc_packets_upload_pieces(nxc_handle *h, int32_t n_pieces, const int64_t *counts,
+                              const double *const *soa);
 int nxc_image_clear(nxc_handle *h);
 int nxc_image_download(nxc_handle *h, double *image /* nx*nz */, uint64_t *counts /* nx*nz */);
 int nxc_counters_get(nxc_handle *h, nxc_counters *out);

@@ -17,7 +17,7 @@ import time
 
 from . import input_classes as spec
 
-HOST_SAMPLER_THREADS = 4        # Outputs of one launch group drawn side by side (Input.run)
+HOST_SAMPLER_THREADS = 8        # Outputs drawn side by side, ahead of the device (Input.run)
 
 # section name in the file -> (attribute on the Input, class that interprets it)
 SECTIONS = (('geometry', spec.Geometry), ('surfaceinteraction', spec.SurfaceInteraction),
@@ -187,16 +187,20 @@ class Input:
                 made += number
                 drawn += size*number
                 print(f'Rank {rank} of {world}: iterations {number + 1} to {stop}.')
-            ahead = None                         # the next launch group's Outputs, being drawn
+            pipeline = None                      # host-drawn Outputs on their way, in order
             pool = None
+            launched = False
+            submitted = number                   # next Output of the pass to hand to the drawers
 
-            def draw_ahead(first, count):
-                # the Outputs of a group are independent draws (seed + k): sample them on a few
-                # threads (NumPy releases the GIL in its loops), integrate them together
-                seeds = [None if seed is None else seed + first + g for g in range(count)]
-                return [pool.submit(Output, self, size, compress=compress, device=device,
-                                    keep_trajectory=keep_trajectory, context=context,
-                                    integrate=False, save=False, seed=s_) for s_ in seeds]
+            def draw_one(k):
+                # Output k of the pass: an independent draw from seed + (its number in the run)
+                s_ = None if seed is None else seed + made + (k - number)
+                def job():
+                    out = Output(self, size, compress=compress, device=device,
+                                 keep_trajectory=keep_trajectory, context=context,
+                                 integrate=False, save=False, seed=s_)
+                    return out.prepare_for_launch()
+                return pool.submit(job)
 
             try:
                 while number < stop:
@@ -206,19 +210,30 @@ class Input:
                     limit = self._group_limit(size, context) if together else 1
                     group = min(stop - number, limit)
                     outs = []
-                    if together and sampler == 'numpy' and (group > 1 or ahead is not None):
+                    if together and sampler == 'numpy' and (group > 1 or pipeline):
+                        # The Outputs are drawn on a few threads (NumPy releases the GIL in its
+                        # loops) a window ahead of the device, and a launch takes whatever is
+                        # drawn by the time the device is free -- at least one Output, at most what
+                        # HBM takes: the first launch starts after the first draws instead of
+                        # after a whole group's, and later launches find their Outputs waiting.
                         if pool is None:
+                            from collections import deque
                             from concurrent.futures import ThreadPoolExecutor
                             pool = ThreadPoolExecutor(max_workers=HOST_SAMPLER_THREADS)
-                        futures = ahead if ahead is not None else draw_ahead(made, group)
-                        group = len(futures)
-                        # ... and the group after this one while this one is integrated
-                        later = min(stop - number - group, self._group_limit(size, context))
-                        ahead = draw_ahead(made + group, later) if later > 0 else None
-                        outs = [f.result() for f in futures]
-                        number += group
-                        drawn += size*group
-                        made += group
+                            pipeline = deque()
+                        window = max(2*HOST_SAMPLER_THREADS, 2*limit)
+                        while submitted < stop and len(pipeline) < window:
+                            pipeline.append(draw_one(submitted))
+                            submitted += 1
+                        outs = [pipeline.popleft().result()]
+                        # (a first launch of a handful keeps the device busy while the rest is drawn)
+                        ready_cap = limit if launched else max(1, min(limit, HOST_SAMPLER_THREADS))
+                        launched = True
+                        while pipeline and pipeline[0].done() and len(outs) < ready_cap:
+                            outs.append(pipeline.popleft().result())
+                        number += len(outs)
+                        drawn += size*len(outs)
+                        made += len(outs)
                         group = 0
                     for g in range(group):
                         number += 1

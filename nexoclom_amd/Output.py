@@ -355,7 +355,19 @@ class Output:
 
     def x0_soa(self):
         """Initial state as the (8, N) struct-of-arrays block the C ABI takes."""
+        ready = getattr(self, '_soa_ready', None)
+        if ready is not None:
+            return ready
         return np.ascontiguousarray(self.X0[STATE_COLS].values.T, dtype=np.float64)
+
+    def prepare_for_launch(self, will_save=True):
+        """What the launch and save() need of X0, made ahead of time (Input.run calls this on the
+        thread that drew the packets, beside the device): the (8, N) upload block and, for
+        save(), the float32 frame of Output.py:528-543."""
+        self._soa_ready = self.x0_soa()
+        if will_save:
+            self._x0_narrow = self._recast(self.X0, NARROW)
+        return self
 
     def _raise_on_counters(self, ctr):
         self.counters = ctr
@@ -541,7 +553,10 @@ class Output:
             lead._device_setup(ctx)
             if not all(getattr(out, '_resident', False) or out.sampler == 'device'
                        for out in outputs):
-                ctx.upload_soa(np.concatenate([out.x0_soa() for out in outputs], axis=1))
+                if hasattr(ctx, 'upload_soa_pieces'):
+                    ctx.upload_soa_pieces([out.x0_soa() for out in outputs])
+                else:
+                    ctx.upload_soa(np.concatenate([out.x0_soa() for out in outputs], axis=1))
             cls._rows_pass(ctx, outputs, step, n_iter)
             for out in outputs:
                 out.nsteps = nsteps
@@ -579,7 +594,9 @@ class Output:
                 if not keep.all():
                     self.X = self.X[keep]
             self.X = self._recast(self.X, NARROW)
-        self.X0 = self._recast(self.X0, NARROW)
+        narrow = self.__dict__.pop('_x0_narrow', None)
+        self.X0 = narrow if narrow is not None else self._recast(self.X0, NARROW)
+        self.__dict__.pop('_soa_ready', None)              # (64 bytes a packet: not kept)
         catalogue = getattr(self.inputs, '_catalogue', None)
         if catalogue is not None:
             self.idnum = len(catalogue) + 1

@@ -1910,6 +1910,37 @@ int nxc_packets_upload(nxc_handle *h, int64_t n, const double *soa0)
     return NXC_OK;
     });
 }
+int nxc_packets_upload_pieces(nxc_handle *h, int32_t n_pieces, const int64_t *counts,
+                              const double *const *soa)
+{
+    return guarded([&]() -> int {
+    if (!h || n_pieces < 1 || !counts || !soa) return fail(NXC_ERR_ARG, "bad arguments");
+    int64_t n = 0;
+    for (int p = 0; p < n_pieces; p++) {
+        if (counts[p] < 0 || (counts[p] && !soa[p])) return fail(NXC_ERR_ARG, "bad piece");
+        n += counts[p];
+    }
+    HIPCHK(hipSetDevice(h->device));
+    int rc = ensure(reinterpret_cast<void **>(&h->d_packets), &h->packets_cap, (size_t)8 * n * sizeof(double));
+    if (rc) return rc;
+    // piece p's column c goes behind the same column of the pieces before it: the resident set is
+    // the concatenation, without the host ever building it
+    int64_t at = 0;
+    for (int p = 0; p < n_pieces; p++) {
+        for (int c = 0; c < 8 && counts[p]; c++)
+            HIPCHK(hipMemcpyAsync(h->d_packets + c * n + at, soa[p] + c * counts[p],
+                                  (size_t)counts[p] * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        at += counts[p];
+    }
+    h->n_packets = n;
+    h->first_id = 0;
+    h->rows_total = -1;
+    if ((rc = order_on_device(h, -1.0, nullptr, 0))) return rc;
+    HIPCHK(stream_sync(h));
+    return NXC_OK;
+    });
+}
+
 int nxc_packets_sample(nxc_handle *h, const nxc_source_desc *d, int64_t n, double *soa_out)
 {
     return guarded([&]() -> int {

@@ -35,7 +35,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_stream_copy_gbs', 'nxc_shader_clock_mhz', 'nxc_pcg64_uniforms',
            'nxc_integrate_const_streamed', 'nxc_image_mode', 'nxc_allreduce_f64',
            'nxc_comm_set_timeout', 'nxc_comm_abort', 'nxc_comm_request_abort',
-           'nxc_comm_test_stall')
+           'nxc_comm_test_stall', 'nxc_packets_upload_pieces')
 ABI_VERSION = 2
 
 
@@ -399,6 +399,16 @@ class Context:
         assert soa.ndim == 2 and soa.shape[0] == 8
         self._check(self.lib.nxc_packets_upload(self._h, C.c_int64(soa.shape[1]), _p(soa)))
         self.n_packets = soa.shape[1]
+
+    def upload_soa_pieces(self, pieces):
+        """The resident set = the (8, n_p) arrays of ``pieces`` one after the other, copied
+        column by column from where they are (no concatenated host copy)."""
+        pieces = [_f64(p) for p in pieces]
+        assert all(p.ndim == 2 and p.shape[0] == 8 for p in pieces)
+        counts = (C.c_int64*len(pieces))(*[p.shape[1] for p in pieces])
+        ptrs = (_dp*len(pieces))(*[_p(p) for p in pieces])
+        self._check(self.lib.nxc_packets_upload_pieces(self._h, C.c_int32(len(pieces)), counts, ptrs))
+        self.n_packets = int(sum(p.shape[1] for p in pieces))
 
     def sample_packets(self, n, seed, first_index=0, download=False, speed_table=None,
                        surface_map=None, pcg64=None, piece=None, **src):

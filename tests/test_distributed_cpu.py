@@ -232,7 +232,8 @@ def _worker_two_stage(rank, world, port, tmpdir, kind):
     lo, hi = shard_range(passes, rank, world)
     assert len(inputs._catalogue) == hi - lo                       # only this rank's Outputs
     assert [o.npackets for o in inputs._catalogue] == [size]*(hi - lo)
-    assert ctx.calls == [(size*(hi - lo), 0)]                      # ... integrated in one launch
+    # ... integrated in a few launches (whatever was drawn when the device was free)
+    assert sum(n for n, _ in ctx.calls) == size*(hi - lo) and all(n % size == 0 for n, _ in ctx.calls)
     assert los.npackets == size*passes and image.totalsource == los.totalsource
     if rank == 0:
         alone, image1, los1 = flow(None, OracleContext())

@@ -810,13 +810,14 @@ def test_row_stores_spill_to_the_host_when_hbm_is_needed(ctx):
         inputs.run(3000, packs_per_it=1000, seed=4, context=ctx)
     outs = inputs._catalogue
     assert all(o.resident_rows(ctx) is not None and o._X is None for o in outs)
-    store = outs[0]._store
-    assert all(o._store is store for o in outs) and store.total == sum(o._nrows for o in outs)
+    # (host-drawn Outputs are launched as they become ready: one store per launch)
+    stores = list({id(o._store): o._store for o in outs}.values())
+    assert sum(s.total for s in stores) == sum(o._nrows for o in outs)
     params = {'quantity': 'column', 'dims': '64,64'}
     before = inputs.produce_image(params, context=ctx)
     free, total = ctx.mem_info()
     ctx.make_room(total)                       # more than can ever be free: everything spills
-    assert store._r is None and all(o.resident_rows(ctx) is None for o in outs)
+    assert all(s._r is None for s in stores) and all(o.resident_rows(ctx) is None for o in outs)
     assert all(o._X is not None and len(o.X) == o._nrows for o in outs)     # rows are on the host now
     after = inputs.produce_image(params, context=ctx)
     assert np.array_equal(before.packet_image, after.packet_image) and before.packet_image.sum() > 100
@@ -888,7 +889,13 @@ def test_input_run_splits_a_launch_group_whose_rows_do_not_fit(ctx, sampler, mon
         return inputs, calls
     whole, calls0 = run(0)
     split, calls1 = run(1500)
-    assert calls0 == [5000] and calls1 == [5000, 2000, 1000, 1000, 3000, 1000, 2000, 1000, 1000]
+    if sampler == 'numpy':
+        # host-drawn Outputs are launched as they become ready: the group sizes depend on timing
+        assert sum(calls0) == 5000 and all(c % 1000 == 0 for c in calls0)
+        done = [c for c in calls1 if c <= 1500]
+        assert sum(done) == 5000 and set(done) == {1000}           # every launch that ran was split down
+    else:
+        assert calls0 == [5000] and calls1 == [5000, 2000, 1000, 1000, 3000, 1000, 2000, 1000, 1000]
     assert len(whole._catalogue) == len(split._catalogue) == 5
     for a, b in zip(whole._catalogue, split._catalogue):
         assert len(a.X) == len(b.X) and a.totalsource == b.totalsource
