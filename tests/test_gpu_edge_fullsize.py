@@ -306,7 +306,9 @@ def test_input_run_rows_at_full_size_against_the_c_oracle(ctx, coracle):
         inputs.run(1e6, seed=99, context=ctx)
     outs = inputs._catalogue
     assert len(outs) == 13 and all(len(o) == 80467 for o in outs)
-    assert all(o._store is outs[0]._store for o in outs)             # one launch, one store
+    # (host-drawn Outputs are launched as they become ready: a few launches, a store each)
+    stores = list({id(o._store): o._store for o in outs}.values())
+    assert 1 <= len(stores) <= 13
     f = H.mercury_forces('Na', 1.3)
     nsteps, n_iter = O.n_output_steps(50000., 30.)
     rng = np.random.default_rng(0)
@@ -338,4 +340,4 @@ def test_input_run_rows_at_full_size_against_the_c_oracle(ctx, coracle):
             assert np.array_equal(rows.lossfrac.values, lossfrac[live].astype(np.float32))
             assert np.array_equal(rows.index.values, i*nsteps + np.nonzero(live)[0])
         out._X = None                                            # keep the host footprint small
-    assert total == outs[0]._store.total and total > 1.2e8
+    assert total == sum(s_.total for s_ in stores) and total > 1.2e8
