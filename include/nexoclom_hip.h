@@ -48,8 +48,10 @@
 extern "C" {
 #endif
 
-/* 2: nxc_source_desc grew (tabulated speeds, surface maps, generator), resident row stores */
-#define NXC_ABI_VERSION 2
+/* 2: nxc_source_desc grew (tabulated speeds, surface maps, generator), resident row stores
+ * 3: bounded waits on collectives (nxc_comm_set_timeout / _abort / _request_abort), nxc_allreduce_f64,
+ *    nxc_packets_upload_pieces, nxc_counters.wave_trips, NXC_ERR_NOMEM / NXC_ERR_INCOMPLETE */
+#define NXC_ABI_VERSION 3
 #define NXC_MAX_LINES 4
 
 typedef enum {

@@ -36,7 +36,7 @@ EXPORTS = ('nxc_abi_version', 'nxc_device_count', 'nxc_last_error_string', 'nxc_
            'nxc_integrate_const_streamed', 'nxc_image_mode', 'nxc_allreduce_f64',
            'nxc_comm_set_timeout', 'nxc_comm_abort', 'nxc_comm_request_abort',
            'nxc_comm_test_stall', 'nxc_packets_upload_pieces')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 NXC_ERR_HIP, NXC_ERR_ARG, NXC_ERR_NO_DEVICE, NXC_ERR_RCCL, NXC_ERR_STATE, NXC_ERR_NOMEM, \

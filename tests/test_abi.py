@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f'{name} declared in nexoclom_hip.h but not exported'
     assert set(names) == set(hip_api.EXPORTS)
-    assert lib.nxc_abi_version() == hip_api.ABI_VERSION == 2
+    assert lib.nxc_abi_version() == hip_api.ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header():
