@@ -391,6 +391,7 @@ struct nxc_handle {
     int rank = 0, nranks = 1;
     bool streamed_pending = false;   // nxc_integrate_const_streamed since the last nxc_synchronize
     bool coll_pending = false;       // a collective sits on `stream` and nobody has waited for it yet
+    hipEvent_t ev_pre_coll = nullptr; // recorded in front of the first pending collective
     std::atomic<bool> abort_requested{false};   // nxc_comm_request_abort (any thread)
     double coll_timeout_s = 120.0;   // nxc_comm_set_timeout / NXC_COLLECTIVE_TIMEOUT_S
     double *d_reduce = nullptr;      // one double for control-plane reductions
@@ -414,6 +415,12 @@ hipError_t stream_sync(nxc_handle *h)
     if (!h->coll_pending || !h->comm || !g_rccl.ok) {
         h->coll_pending = false;
         return hipStreamSynchronize(h->stream);
+    }
+    // what was queued before the collective is this process's own work: it ends by itself, and is
+    // waited for the ordinary way (no polling beside a 40 ms kernel); the deadline runs from there
+    if (h->ev_pre_coll) {
+        const hipError_t e = hipEventSynchronize(h->ev_pre_coll);
+        if (e != hipSuccess) { h->coll_pending = false; return e; }
     }
     timespec t0{};
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1416,6 +1423,7 @@ int nxc_destroy(nxc_handle *h)
     pool_flush(h);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev_pre_coll) (void)hipEventDestroy(h->ev_pre_coll);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     for (hipEvent_t ev : h->ev_piece)
@@ -2560,6 +2568,17 @@ int nxc_comm_set_timeout(nxc_handle *h, double seconds)
     return NXC_OK;
 }
 
+// In front of a collective: the event that separates this process's own queued work from it.
+static int mark_collective(nxc_handle *h)
+{
+    if (!h->coll_pending) {
+        if (!h->ev_pre_coll) HIPCHK(hipEventCreateWithFlags(&h->ev_pre_coll, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_pre_coll, h->stream));
+    }
+    h->coll_pending = true;
+    return NXC_OK;
+}
+
 int nxc_comm_request_abort(nxc_handle *h)
 {
     if (!h) return fail(NXC_ERR_ARG, "null handle");
@@ -2572,10 +2591,10 @@ int nxc_comm_test_stall(nxc_handle *h, double seconds)
     if (!h || !(seconds >= 0.0) || seconds > 30.0) return fail(NXC_ERR_ARG, "bad arguments");
     if (!h->comm) return fail(NXC_ERR_STATE, "nxc_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
+    if (int rc = mark_collective(h)) return rc;
     hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, h->stream,
                        (unsigned long long)(seconds * 1e8), (unsigned long long *)nullptr);
     HIPCHK(hipGetLastError());
-    h->coll_pending = true;
     return NXC_OK;
 }
 
@@ -2612,7 +2631,7 @@ int nxc_image_allreduce(nxc_handle *h)
     HIPCHK(hipSetDevice(h->device));
     if (int rc = refuse_after_abort_request(h)) return rc;
     // one collective: weights and (integer-valued fp64) counts are interleaved in one array
-    h->coll_pending = true;
+    if (int rc = mark_collective(h)) return rc;
     NCCLCHK(g_rccl.AllReduce(h->d_image, h->d_image, 2 * h->npix, ncclFloat64, ncclSum, h->comm,
                              h->stream));
     return NXC_OK;
@@ -2632,8 +2651,8 @@ static int allreduce_host(nxc_handle *h, double *values, int64_t n, ncclRedOp_t 
         d = h->d_reduce_n;
     }
     if (int rc = refuse_after_abort_request(h)) return rc;
+    if (int rc = mark_collective(h)) return rc;
     HIPCHK(hipMemcpyAsync(d, values, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
-    h->coll_pending = true;
     NCCLCHK(g_rccl.AllReduce(d, d, (size_t)n, ncclFloat64, op, h->comm, h->stream));
     HIPCHK(hipMemcpyAsync(values, d, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(stream_sync(h));
