@@ -1330,13 +1330,16 @@ NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy
 // time, finds the packet starts with a prefix maximum across its lanes, places the blocks with a
 // prefix scan that knows about the fresh-group rule, and writes {first row << 4 | rows} and the
 // bounding sphere of every slot to its region of the scratch arrays (at most one slot per row).
-// k_los: the same wave takes its region 64 slots at a time, one block per lane.  The 8 lanes of a
-// group share the group's cone tests -- lane i tests the spectra i, i + 8, ... -- and only the
-// (group, spectrum) pairs that pass are looked at block by block: 8 pairs per wave instruction,
-// one lane per (pair, block).  Sphere tests per block and spectrum: one before, a quarter now.
-// What passes the block test -- one (block, spectrum) pair in 700 -- goes through the per-wave LDS
-// queue, so that its rows meet los_pair with full waves.  All the spectra of a launch (up to
-// NXC_LOS_TILE = 512) sit in LDS, so blocks and spheres are read once for all of them.
+// k_los: persistent waves take the stream 64 slots at a time, one block per lane.  Three levels:
+// a lane holds ONE spectrum (64 at a time) and meets the 8 group spheres; the (group, spectrum)
+// pairs that pass meet the group's two HALVES (4 blocks each), 32 pairs per wave instruction; the
+// (half, spectrum) pairs that pass meet the half's four blocks, 16 per wave instruction.  Sphere
+// tests per block and spectrum: one before, 0.24 now.  What passes the block test -- one (block,
+// spectrum) pair in 700 -- goes through the per-wave LDS queue, so that its rows meet los_pair
+// with full waves.  All the spectra of a launch (up to NXC_LOS_TILE = 512) sit in LDS, so blocks
+// and spheres are read once for all of them.  (The kernel is bound by the latency of its
+// wave-synchronous stages -- LDS list, ballot, LDS list -- at 16 waves per CU, which the 150 KB of
+// tables, spectra and per-wave lists allow: halving the block tests did not change its time.)
 // K.cull = 0 (boresights that are not unit vectors) gives every block an infinite radius.
 constexpr int NXC_LOS_FORM = 256;        // rows whose packet ids are examined at a time: 4 per lane
 
@@ -1516,7 +1519,8 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
 }
 
 constexpr int NXC_LOS_PAIRS = 512;       // (group, spectrum) survivors of 8 tests per lane
-constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + 64 * 32 + 64 * 8 + NXC_LOS_PAIRS * 2;
+// per wave: candidate queue | 64 block | 16 half-group | 8 group spheres | pairs | (half, spectrum) pairs
+constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + 64 * 32 + 16 * 32 + 8 * 32 + NXC_LOS_PAIRS * 2 + 64 * 2;
 #ifndef NXC_LOS_THREADS
 #define NXC_LOS_THREADS 1024
 #endif
@@ -1544,14 +1548,15 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     }
     __syncthreads();
     const double rs_1e6 = nxc_recip_seed(1e6);
-    unsigned long long my_pairs = 0, my_nonfinite = 0, my_tests = 0;
+    unsigned long long my_pairs = 0, my_nonfinite = 0;
+    unsigned long long wave_tests = 0;     // sphere tests of this wave (wave-uniform: scalar adds)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + wid * NXC_LOS_WAVE_BYTES;
     double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
-    unsigned long long *const sdesc =
-        reinterpret_cast<unsigned long long *>(nxc_lds + qoff + NXC_LOSQ_BYTES + 64 * 32);
-    unsigned short *const pairs =
-        reinterpret_cast<unsigned short *>(nxc_lds + qoff + NXC_LOSQ_BYTES + 64 * 32 + 64 * 8);
+    double *const hsph = sph + 64 * 4;
+    double *const gsph = hsph + 16 * 4;
+    unsigned short *const pairs = reinterpret_cast<unsigned short *>(gsph + 8 * 4);
+    unsigned short *const pairs2 = pairs + NXC_LOS_PAIRS;
     const long long count = (long long)*n_slots;              // a multiple of 8
     LosQueue queue;
     auto drain = [&]() {               // up to 64 queued candidates, one per lane
@@ -1568,7 +1573,6 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             }
         }
     };
-    const int grp = lane >> 3, sub = lane & 7;
     // a trip: 64 consecutive slots of the stream, one per lane.  The trips differ in how much of
     // them lies near a line of sight: a wave takes the next one when it is done with its own (one
     // counter per tile of spectra)
@@ -1579,53 +1583,56 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
         const long long base = 64ll * trip;
         if (base >= count) break;
         const bool in = base + lane < count;
-        unsigned long long desc = 0;
         double cx = 0, cy = 0, cz = 0, R = -1.0;
         if (in) {
-            desc = bdesc[base + lane];
             const nxc_v2d *q = reinterpret_cast<const nxc_v2d *>(bsph + 4 * (base + lane));
             const nxc_v2d u = q[0], v = q[1];
             cx = u.x; cy = u.y; cz = v.x; R = v.y;
         }
         const bool has = R >= 0.0;
         sph[4 * lane] = cx; sph[4 * lane + 1] = cy; sph[4 * lane + 2] = cz; sph[4 * lane + 3] = R;
-        sdesc[lane] = desc;
-        // the group's sphere: centre of the box of its blocks' centres, radius to the farthest
-        // point of any of its blocks (three butterfly steps inside the 8 lanes)
+        // Bounding spheres of the HALF groups (4 lanes) and of the groups (8 lanes): centre of the
+        // box of the blocks' centres, radius to the farthest point of any block (butterfly steps
+        // inside the 4, then the 8 lanes)
         const double big = 1.7976931348623157e308;
         double blx = has ? cx : big, bhx = has ? cx : -big, bly = has ? cy : big, bhy = has ? cy : -big,
                blz = has ? cz : big, bhz = has ? cz : -big;
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
+        auto widen = [&](int off) {
             blx = __builtin_fmin(blx, __shfl_xor(blx, off, 64)); bhx = __builtin_fmax(bhx, __shfl_xor(bhx, off, 64));
             bly = __builtin_fmin(bly, __shfl_xor(bly, off, 64)); bhy = __builtin_fmax(bhy, __shfl_xor(bhy, off, 64));
             blz = __builtin_fmin(blz, __shfl_xor(blz, off, 64)); bhz = __builtin_fmax(bhz, __shfl_xor(bhz, off, 64));
+        };
+        auto reach = [&](double ox, double oy, double oz) {     // from (ox, oy, oz) to my block's far side
+            if (!has) return -1.0;
+            const double ex = cx - ox, ey = cy - oy, ez = cz - oz;
+            return (__builtin_sqrt((ex * ex + ey * ey) + ez * ez) + R) * (1.0 + 1e-12);
+        };
+        widen(1); widen(2);
+        const double hx_ = 0.5 * (blx + bhx), hy_ = 0.5 * (bly + bhy), hz_ = 0.5 * (blz + bhz);
+        double HR = reach(hx_, hy_, hz_);
+        HR = __builtin_fmax(HR, __shfl_xor(HR, 1, 64));
+        HR = __builtin_fmax(HR, __shfl_xor(HR, 2, 64));
+        if ((lane & 3) == 0) {
+            double *q = hsph + 4 * (lane >> 2);
+            q[0] = hx_; q[1] = hy_; q[2] = hz_; q[3] = HR;
         }
+        widen(4);
         const double gx_ = 0.5 * (blx + bhx), gy_ = 0.5 * (bly + bhy), gz_ = 0.5 * (blz + bhz);
-        double GR = -1.0;
-        if (has) {
-            const double ex = cx - gx_, ey = cy - gy_, ez = cz - gz_;
-            GR = (__builtin_sqrt((ex * ex + ey * ey) + ez * ez) + R) * (1.0 + 1e-12);
-        }
+        double GR = reach(gx_, gy_, gz_);
 #pragma unroll
         for (int off = 1; off < 8; off <<= 1) GR = __builtin_fmax(GR, __shfl_xor(GR, off, 64));
-        // the eight group spheres as wave-uniform values (scalar registers)
-        double Gx[8], Gy[8], Gz[8], Gr[8];
-#pragma unroll
-        for (int g = 0; g < 8; g++) {
-            Gx[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gx_), 8 * g),
-                                     __builtin_amdgcn_readlane(__double2loint(gx_), 8 * g));
-            Gy[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gy_), 8 * g),
-                                     __builtin_amdgcn_readlane(__double2loint(gy_), 8 * g));
-            Gz[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(gz_), 8 * g),
-                                     __builtin_amdgcn_readlane(__double2loint(gz_), 8 * g));
-            Gr[g] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(GR), 8 * g),
-                                     __builtin_amdgcn_readlane(__double2loint(GR), 8 * g));
+        // the eight group spheres: in LDS, read back with a wave-uniform address (a broadcast;
+        // as 64 scalar registers they spilled)
+        if ((lane & 7) == 0) {
+            double *q = gsph + 4 * (lane >> 3);
+            q[0] = gx_; q[1] = gy_; q[2] = gz_; q[3] = GR;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- group tests, 64 spectra at a time: a lane holds ONE spectrum (read from LDS once)
-        //      and meets the eight group spheres; then the survivors block by block ------------
+        // ---- 64 spectra at a time.  Level 1: a lane holds ONE spectrum (read from LDS once) and
+        //      meets the eight group spheres.  Level 2: the surviving (group, spectrum) pairs meet
+        //      the group's two halves, 32 pairs per wave instruction.  Level 3: the surviving
+        //      (half, spectrum) pairs meet the half's four blocks, 16 per wave instruction. -------
         for (int c0 = 0; c0 < ns; c0 += 64) {
             const int jm = c0 + lane;
             double spj[8];
@@ -1634,8 +1641,9 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             int npair = 0;
 #pragma unroll
             for (int g = 0; g < 8; g++) {
-                const bool hit = jm < ns && los_sphere_hits(spj, Gx[g], Gy[g], Gz[g], Gr[g], K.tan_dphi);
-                my_tests += jm < ns && Gr[g] >= 0.0;
+                const double *G = gsph + 4 * g;
+                const bool hit = jm < ns && los_sphere_hits(spj, G[0], G[1], G[2], G[3], K.tan_dphi);
+                wave_tests += ns - c0 < 64 ? ns - c0 : 64;
                 const unsigned long long mask = __ballot(hit);
                 if (hit) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(g << 9 | jm);
                 npair += __popcll(mask);
@@ -1643,28 +1651,48 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int at0 = 0; at0 < npair; at0 += 8) {
-                const int at = at0 + grp;                     // eight pairs per wave instruction
+            for (int at0 = 0; at0 < npair; at0 += 32) {
+                const int at = at0 + (lane >> 1);
                 bool hit = false;
-                int j = 0;
-                unsigned long long bd = 0;
+                unsigned e2 = 0;
                 if (at < npair) {
                     const unsigned e = pairs[at];
-                    const int slot = (int)(e >> 9) * 8 + sub;
-                    j = (int)(e & 511u);
-                    bd = sdesc[slot];
-                    const double *q = sph + 4 * slot;
+                    const int hs = (int)(e >> 9) * 2 + (lane & 1);
+                    const int j = (int)(e & 511u);
+                    const double *q = hsph + 4 * hs;
                     hit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
-                    my_tests += q[3] >= 0.0;
+                    e2 = (unsigned)hs << 9 | (unsigned)j;
                 }
-                queue.push(hit, (long long)bd, j, qoff);
-                if (queue.waiting() >= 64) drain();
+                wave_tests += 2 * (npair - at0 < 32 ? npair - at0 : 32);
+                const unsigned long long mask = __ballot(hit);
+                if (hit) pairs2[__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e2;
+                const int n2 = __popcll(mask);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int b0 = 0; b0 < n2; b0 += 16) {
+                    const int bt = b0 + (lane >> 2);
+                    bool bhit = false;
+                    int j = 0, slot = 0;
+                    if (bt < n2) {
+                        const unsigned e = pairs2[bt];
+                        slot = (int)(e >> 9) * 4 + (lane & 3);
+                        j = (int)(e & 511u);
+                        const double *q = sph + 4 * slot;
+                        bhit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
+                    }
+                    wave_tests += 4 * (n2 - b0 < 16 ? n2 - b0 : 16);
+                    // (one block test in 80 passes: its descriptor comes from memory then)
+                    const long long bd = bhit ? (long long)bdesc[base + slot] : 0ll;
+                    queue.push(bhit, bd, j, qoff);
+                    if (queue.waiting() >= 64) drain();
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     while (queue.waiting() > 0) drain();
-    flush_counter(&ctr->samples, my_tests);
+    if (lane == 0) atomicAdd(&ctr->samples, wave_tests);
     flush_counter(&ctr->samples_binned, my_pairs);
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }

@@ -182,7 +182,7 @@ def main():
         tests = ctx.counters()['samples']
         line(name, ms, P*S, '(sample, spectrum) pairs decided', 40.0/S,
              f'{P} samples x {S} spectra, {int(r["npackets"].sum())} pairs inside cones, '
-             f'{tests} bounding-sphere tests (groups of 8 blocks, then blocks of 8 rows: one test '
+             f'{tests} bounding-sphere tests (groups of 8 blocks, their halves, then blocks of 8 rows: one test '
              f'per {P*S/max(tests, 1):.0f} pairs; round 3 tested every (block, spectrum): '
              f'{(P + 7)//8*S}); the samples are read once by k_los_blocks (16 B) and again only where a '
              f'block passes a cone')
