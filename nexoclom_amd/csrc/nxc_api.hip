@@ -1049,7 +1049,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
     // ... | per-wave candidate queues
     const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double) +
-                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES;
+                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 16;   // + the trip counter
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
     // device scratch: blob | sc | ladder | radiance | npackets | included | used
@@ -1083,20 +1083,32 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
         const int64_t max_regions = (slab + NXC_LOS_FORM - 1) / NXC_LOS_FORM;
         const size_t max_slots = (size_t)(slab + 8 * max_regions);
         const size_t o_desc = 0, o_sph = (max_slots * 8 + 255) & ~size_t(255),
-                     o_n = o_sph + max_slots * 32, o_next = o_n + 256;
+                     o_n = o_sph + max_slots * 32;
+        // the list of (row, spectrum) pairs near a cone: chunks of 64 (k_los -> k_los_pairs); when
+        // it is full k_los decides the pairs itself
+        constexpr int pair_chunks = 1 << 15;
+        const size_t o_fill = o_n + 256, o_list = o_fill + (size_t)pair_chunks * 4;
         if ((rc = ensure(reinterpret_cast<void **>(&h->d_losblk), &h->losblk_cap,
-                         o_next + (size_t)tiles * 4)))
+                         o_list + (size_t)pair_chunks * 64 * 8)))
             return rc;
+        size_t lds_pairs = ((stage_bytes + 31) & ~size_t(31)) + (size_t)((d->n_ladder + 3) & ~int64_t(3)) * 8;
+        if (lds_pairs > 160 * 1024) return fail(NXC_ERR_ARG, "the ladder of ball centres exceeds the LDS");
+        // the per-spectrum sums of a workgroup in LDS when they leave room for two workgroups per CU
+        const int lds_sums = lds_pairs + (size_t)S * 16 <= 80 * 1024 ? 1 : 0;
+        if (lds_sums) lds_pairs += (size_t)S * 16;
+        if ((rc = prep_kernel(k_los_pairs<T, I>, lds_pairs))) return rc;
+        unsigned *pair_used = reinterpret_cast<unsigned *>(h->d_losblk + o_n + 8);
+        unsigned *pair_fill = reinterpret_cast<unsigned *>(h->d_losblk + o_fill);
+        unsigned long long *pair_list = reinterpret_cast<unsigned long long *>(h->d_losblk + o_list);
         unsigned long long *bdesc = reinterpret_cast<unsigned long long *>(h->d_losblk + o_desc);
         double *bsph = reinterpret_cast<double *>(h->d_losblk + o_sph);
         unsigned long long *n_slots = reinterpret_cast<unsigned long long *>(h->d_losblk + o_n);
-        unsigned *next_trip = reinterpret_cast<unsigned *>(h->d_losblk + o_next);
         if ((rc = begin_timed(h))) return rc;
         for (int64_t first = 0; first < P; first += slab) {
             const int64_t n = std::min<int64_t>(slab, P - first);
             const int64_t regions = (n + NXC_LOS_FORM - 1) / NXC_LOS_FORM;
             K.row_base = first;
-            HIPCHK(hipMemsetAsync(n_slots, 0, 256 + (size_t)tiles * 4, st));      // + the trip counters
+            HIPCHK(hipMemsetAsync(n_slots, 0, 256 + (size_t)pair_chunks * 4, st));   // counters + chunk fills
             hipLaunchKernelGGL((k_los_blocks<T, I>),
                                dim3((unsigned)((regions + NXC_LOS_BLOCKS_THREADS / 64 - 1) /
                                                (NXC_LOS_BLOCKS_THREADS / 64))),
@@ -1108,9 +1120,21 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
             hipLaunchKernelGGL((k_los<T, I>), dim3((unsigned)groups, tiles),
                                dim3(NXC_LOS_THREADS), lds, st, K, base + o_blob,
                                (int64_t)stage_bytes, S, reinterpret_cast<const double *>(base + o_sc),
-                               n_slots, bdesc, bsph, next_trip, dx + first, dy + first,
-                               dz + first, dvy + first, dfrac + first,
+                               n_slots, bdesc, bsph, pair_list, pair_fill, pair_used, pair_chunks,
+                               dx + first, dy + first, dz + first, dvy + first, dfrac + first,
                                d_index ? d_index + first : d_index,
+                               reinterpret_cast<const double *>(base + o_lad),
+                               reinterpret_cast<double *>(base + o_rad),
+                               reinterpret_cast<unsigned long long *>(base + o_np),
+                               included ? base + o_inc : nullptr, (long long)used_cap,
+                               used_pairs ? reinterpret_cast<long long *>(base + o_used) : nullptr,
+                               reinterpret_cast<unsigned long long *>(base + o_nu), h->d_ctr);
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL((k_los_pairs<T, I>), dim3((unsigned)(h->n_cu * 2)), dim3(NXC_BLOCK),
+                               lds_pairs, st, K, base + o_blob, (int64_t)stage_bytes, S,
+                               reinterpret_cast<const double *>(base + o_sc), pair_list, pair_fill,
+                               pair_used, pair_chunks, lds_sums, dx + first, dy + first, dz + first,
+                               dvy + first, dfrac + first, d_index ? d_index + first : d_index,
                                reinterpret_cast<const double *>(base + o_lad),
                                reinterpret_cast<double *>(base + o_rad),
                                reinterpret_cast<unsigned long long *>(base + o_np),

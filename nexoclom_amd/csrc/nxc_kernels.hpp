@@ -1158,14 +1158,25 @@ constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile, all of them in LD
 #endif
 constexpr int NXC_LOS_BLOCK = NXC_LOS_BLOCK_N;   // consecutive stored samples tested together first
 
+// The cheap part of the pair test: in front of the spacecraft, this side of the planet cut-off,
+// inside a cone a hair wider than the real one.  What passes goes on to los_pair (one pair in
+// 1.4e4 for the bench cloud).  A non-finite coordinate fails every comparison, as in the reference.
+NXC_DEV bool los_pair_maybe(const LosK &K, const double *__restrict__ sp, double px, double py, double pz)
+{
+    const double rx = px - sp[0], ry = py - sp[1], rz = pz - sp[2];
+    const double q = (rx * sp[3] + ry * sp[4]) + rz * sp[5];
+    if (!(q > 0.0) || !(q < sp[6])) return false;
+    const double d2 = (rx * rx + ry * ry) + rz * rz;
+    return q * q >= K.cos_thr2_lo * d2;
+}
+
 // One (stored sample, spectrum) pair, exactly as the reference decides and weighs it
 // (compute_iteration.py:177-213).  sp: the spectrum's eight tile values.
-template <typename T, typename I>
+// (vy_p, frac_p, idx_p: the sample's radial velocity, fraction and slot in `included`, loaded by the
+// caller together with its coordinates; ladder: global or LDS)
 NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spectrum, int64_t p,
-                      double px, double py, double pz, const T *__restrict__ vy,
-                      const T *__restrict__ frac, const I *__restrict__ index,
-                      const double *__restrict__ ladder, double *__restrict__ radiance,
-                      unsigned long long *__restrict__ npackets,
+                      double px, double py, double pz, double vy_p, double frac_p, long long idx_p,
+                      const double *ladder, double *radiance, unsigned long long *npackets,
                       unsigned char *__restrict__ included, long long used_cap,
                       long long *__restrict__ used_pairs, unsigned long long *__restrict__ n_used,
                       double rs_1e6, unsigned long long &my_pairs, unsigned long long &my_nonfinite)
@@ -1176,6 +1187,10 @@ NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spec
     if (!(q > 0.0) || !(q < sp[6])) return;                        // cone in front; planet cut :185
     const double d2 = (rx * rx + ry * ry) + rz * rz;
     if (!(q * q >= K.cos_thr2_lo * d2)) return;                    // coarse cone test
+#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 1   /* timing experiments: see tools/gpu_exp_los_stages.sh */
+    my_pairs++;
+    return;
+#endif
     const double dist = nxc_sqrt(d2);                              // :177
     double cosang = nxc_div(q, dist);                              // :179
     cosang = cosang > 1.0 ? 1.0 : cosang;                          // :180
@@ -1196,12 +1211,12 @@ NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spec
     if (!cand) return;
     // the weight of the sample (ModelResult.py:150-161, out_of_shadow = 1); pairs that get here
     // are one in 1e4 of those tested, so it is formed per pair rather than kept per sample
-    const double radvel = (double)vy[p] + K.vrplanet;
+    const double radvel = vy_p + K.vrplanet;
     double gg = K.n_lines > 0 ? lut_interp(lut_view(K.line[0]), radvel) : 0.0;
 #pragma unroll
     for (int l = 1; l < 4; l++)
         if (l < K.n_lines) gg += lut_interp(lut_view(K.line[l]), radvel);
-    const double weight = nxc_div_const((double)frac[p] * gg, 1e6, rs_1e6);   // 1e6 is mid-range
+    const double weight = nxc_div_const(frac_p * gg, 1e6, rs_1e6);   // 1e6 is mid-range
     if (!(__builtin_fabs(weight) <= 1.7976931348623157e308) || radvel != radvel) my_nonfinite++;
     const double ds = dist * K.sin_dphi;
     const double apix = (3.141592653589793 * (ds * ds)) * K.unit_cm2;         // :194-195
@@ -1209,10 +1224,10 @@ NXC_DEV void los_pair(const LosK &K, const double *__restrict__ sp, int64_t spec
     const double hx = xs + bx * q, hy = ys + by * q, hz = zs + bz * q;          // :202-206
     const bool lit = ((hx * hx + hz * hz) > 0x1.0000000000001p+0) || (hy < 0.0);
     wtemp = lit ? wtemp : wtemp * 0.0;
-    if (wtemp != 0.0) unsafeAtomicAdd(&radiance[spectrum], wtemp);
+    if (wtemp != 0.0) unsafeAtomicAdd(&radiance[spectrum], wtemp);     // (global, or a workgroup's LDS copy)
     atomicAdd(&npackets[spectrum], 1ull);
     my_pairs++;
-    if (included) included[index ? (long long)index[p] - K.index_shift : p + K.row_base] = 1;
+    if (included) included[idx_p] = 1;
     if (used_pairs && wtemp > 0.0) {
         const unsigned long long slot = atomicAdd(n_used, 1ull);
         if ((long long)slot < used_cap) {
@@ -1529,7 +1544,8 @@ __global__ void __launch_bounds__(NXC_LOS_THREADS)
 k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
       const double *__restrict__ sc, const unsigned long long *__restrict__ n_slots,
       const unsigned long long *__restrict__ bdesc, const double *__restrict__ bsph,
-      unsigned *__restrict__ next_trip,
+      unsigned long long *__restrict__ pair_list, unsigned *__restrict__ pair_fill,
+      unsigned *__restrict__ pair_used, int pair_chunks,
       const T *__restrict__ x, const T *__restrict__ y, const T *__restrict__ z,
       const T *__restrict__ vy, const T *__restrict__ frac, const I *__restrict__ index,
       const double *__restrict__ ladder, double *__restrict__ radiance,
@@ -1559,28 +1575,66 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     unsigned short *const pairs2 = pairs + NXC_LOS_PAIRS;
     const long long count = (long long)*n_slots;              // a multiple of 8
     LosQueue queue;
+    // The rows of the queued blocks meet the cheap part of the pair test; what passes -- one
+    // (row, spectrum) pair in 25 of those, a few lanes at a time -- is not decided here (the exact
+    // test, the ball search, two table lookups, three divisions and the atomics would run for one
+    // or two live lanes per wave instruction: a quarter of this kernel's time) but written to a
+    // list in memory, 64 to a chunk, which k_los_pairs works through with full waves.  A wave
+    // fills chunks of its own (one returning atomic per chunk); when the list is full the pair is
+    // decided on the spot.
+    int cur_chunk = -1, cur_fill = 0;                 // wave-uniform
     auto drain = [&]() {               // up to 64 queued candidates, one per lane
         long long qb = 0;
         int qj = 0;
-        if (queue.pop(qoff, qb, qj)) {
-            const int64_t q0 = qb >> 4;
-            const int qn = (int)(qb & 15);
-            for (int s_ = 0; s_ < qn; s_++) {
-                const int64_t p = q0 + s_;
-                los_pair<T, I>(K, tile + qj * 8, s0 + qj, p, (double)x[p], (double)y[p], (double)z[p],
-                               vy, frac, index, ladder, radiance, npackets, included, used_cap,
-                               used_pairs, n_used, rs_1e6, my_pairs, my_nonfinite);
+        const bool mine = queue.pop(qoff, qb, qj);
+        const int64_t q0 = qb >> 4;
+        const int qn = mine ? (int)(qb & 15) : 0;
+        for (int s_ = 0; s_ < NXC_LOS_BLOCK; s_++) {
+            if (__ballot(s_ < qn) == 0) break;
+            const int64_t p = q0 + s_;
+            double px = 0, py = 0, pz = 0;
+            bool hit = false;
+            if (s_ < qn) {
+                px = (double)x[p]; py = (double)y[p]; pz = (double)z[p];
+                hit = los_pair_maybe(K, tile + qj * 8, px, py, pz);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m == 0) continue;
+            const int n = __popcll(m);
+            if (cur_chunk < 0 || cur_fill + n > 64) {
+                if (cur_chunk >= 0 && cur_chunk < pair_chunks && lane == 0) pair_fill[cur_chunk] = (unsigned)cur_fill;
+                unsigned c = 0;
+                if (lane == 0) c = atomicAdd(pair_used, 1u);
+                cur_chunk = __builtin_amdgcn_readfirstlane((int)c);
+                cur_fill = 0;
+            }
+            if (cur_chunk < pair_chunks) {
+                if (hit)
+                    pair_list[(size_t)cur_chunk * 64 + cur_fill + __popcll(m & ((1ull << lane) - 1ull))] =
+                        (unsigned long long)p << 32 | (unsigned long long)(s0 + qj);
+                cur_fill += n;
+            } else if (hit) {
+                los_pair(K, tile + qj * 8, s0 + qj, p, px, py, pz, (double)vy[p], (double)frac[p],
+                         index ? (long long)index[p] - K.index_shift : p + K.row_base, ladder, radiance,
+                         npackets, included, used_cap, used_pairs, n_used, rs_1e6, my_pairs, my_nonfinite);
             }
         }
     };
     // a trip: 64 consecutive slots of the stream, one per lane.  The trips differ in how much of
-    // them lies near a line of sight: a wave takes the next one when it is done with its own (one
-    // counter per tile of spectra)
+    // them lies near a line of sight, so the waves of a workgroup take theirs dynamically -- from a
+    // counter in LDS over the workgroup's own trips (every gridDim.x-th: a returning atomic on ONE
+    // global address runs at 80 million a second, which for 3e4 trips was two thirds of the kernel)
+    // (the counter lives in the dynamic block, behind the last wave's lists: the kernels address
+    // LDS from its start, so nothing static may sit in front)
+    unsigned *const wg_next = reinterpret_cast<unsigned *>(
+        nxc_lds + K.tile_off + NXC_LOS_TILE * 64 + (blockDim.x >> 6) * NXC_LOS_WAVE_BYTES);
+    if (threadIdx.x == 0) *wg_next = 0;
+    __syncthreads();
     for (;;) {
-        unsigned trip = 0;
-        if (lane == 0) trip = atomicAdd(next_trip + blockIdx.y, 1u);
-        trip = (unsigned)__builtin_amdgcn_readfirstlane((int)trip);
-        const long long base = 64ll * trip;
+        unsigned k = 0;
+        if (lane == 0) k = atomicAdd(wg_next, 1u);
+        k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+        const long long base = 64ll * ((long long)blockIdx.x + (long long)k * gridDim.x);
         if (base >= count) break;
         const bool in = base + lane < count;
         double cx = 0, cy = 0, cz = 0, R = -1.0;
@@ -1633,24 +1687,37 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
         //      meets the eight group spheres.  Level 2: the surviving (group, spectrum) pairs meet
         //      the group's two halves, 32 pairs per wave instruction.  Level 3: the surviving
         //      (half, spectrum) pairs meet the half's four blocks, 16 per wave instruction. -------
+#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 4
+        my_pairs += (unsigned long long)(gsph[3] > 0.0);
+        if (ns > 0) continue;
+#endif
         for (int c0 = 0; c0 < ns; c0 += 64) {
             const int jm = c0 + lane;
             double spj[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) spj[c] = tile[(jm < ns ? jm : 0) * 8 + c];
             int npair = 0;
+            // the eight tests first (independent chains the scheduler can interleave), then the
+            // eight compactions
+            bool ghit[8];
 #pragma unroll
             for (int g = 0; g < 8; g++) {
                 const double *G = gsph + 4 * g;
-                const bool hit = jm < ns && los_sphere_hits(spj, G[0], G[1], G[2], G[3], K.tan_dphi);
-                wave_tests += ns - c0 < 64 ? ns - c0 : 64;
-                const unsigned long long mask = __ballot(hit);
-                if (hit) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(g << 9 | jm);
+                ghit[g] = jm < ns && los_sphere_hits(spj, G[0], G[1], G[2], G[3], K.tan_dphi);
+            }
+            wave_tests += 8 * (ns - c0 < 64 ? ns - c0 : 64);
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const unsigned long long mask = __ballot(ghit[g]);
+                if (ghit[g]) pairs[npair + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(g << 9 | jm);
                 npair += __popcll(mask);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 3
+            my_pairs += npair; npair = 0;
+#endif
             for (int at0 = 0; at0 < npair; at0 += 32) {
                 const int at = at0 + (lane >> 1);
                 bool hit = false;
@@ -1684,15 +1751,81 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                     wave_tests += 4 * (n2 - b0 < 16 ? n2 - b0 : 16);
                     // (one block test in 80 passes: its descriptor comes from memory then)
                     const long long bd = bhit ? (long long)bdesc[base + slot] : 0ll;
+#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 2
+                    my_pairs += bhit && bd != 0;
+#else
                     queue.push(bhit, bd, j, qoff);
                     if (queue.waiting() >= 64) drain();
+#endif
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
     }
     while (queue.waiting() > 0) drain();
+    if (cur_chunk >= 0 && cur_chunk < pair_chunks && lane == 0) pair_fill[cur_chunk] = (unsigned)cur_fill;
     if (lane == 0) atomicAdd(&ctr->samples, wave_tests);
+    flush_counter(&ctr->samples_binned, my_pairs);
+    flush_counter(&ctr->nonfinite, my_nonfinite);
+}
+
+// The pairs k_los found near a cone, decided and weighed as the reference does it
+// (compute_iteration.py:177-213) -- 64 of them per wave instruction.
+template <typename T, typename I>
+__global__ void __launch_bounds__(NXC_BLOCK)
+k_los_pairs(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t S,
+            const double *__restrict__ sc, const unsigned long long *__restrict__ pair_list,
+            const unsigned *__restrict__ pair_fill, const unsigned *__restrict__ pair_used,
+            int pair_chunks, int lds_sums, const T *__restrict__ x, const T *__restrict__ y,
+            const T *__restrict__ z, const T *__restrict__ vy, const T *__restrict__ frac,
+            const I *__restrict__ index, const double *__restrict__ ladder,
+            double *__restrict__ radiance, unsigned long long *__restrict__ npackets,
+            unsigned char *__restrict__ included, long long used_cap,
+            long long *__restrict__ used_pairs, unsigned long long *__restrict__ n_used,
+            DevCounters *__restrict__ ctr)
+{
+    stage_tables(blob, stage_bytes);                   // g-value tables; nxc_log's table in the header
+    // the ladder of ball centres next to them: a pair walks seven of its rungs
+    double *const lad = reinterpret_cast<double *>(nxc_lds + ((stage_bytes + 31) & ~31ll));
+    for (int k = threadIdx.x; k < K.n_ladder; k += blockDim.x) lad[k] = ladder[k];
+    // The sums of a workgroup's pairs are formed in LDS and handed over once per touched spectrum
+    // (lds_sums: S of them fit).  A line of sight through the densest part of the cloud collects
+    // tens of thousands of pairs, and atomics on ONE global address run at 80 million a second:
+    // added straight to memory they took 0.5 ms for 3.9e5 pairs.
+    double *const racc = lad + ((K.n_ladder + 3) & ~3);
+    unsigned long long *const nacc = reinterpret_cast<unsigned long long *>(racc + (lds_sums ? S : 0));
+    if (lds_sums)
+        for (int k = threadIdx.x; k < S; k += blockDim.x) { racc[k] = 0.0; nacc[k] = 0ull; }
+    __syncthreads();
+    const double rs_1e6 = nxc_recip_seed(1e6);
+    unsigned long long my_pairs = 0, my_nonfinite = 0;
+    const int lane = threadIdx.x & 63;
+    const unsigned used = *pair_used;
+    const long long chunks = used < (unsigned)pair_chunks ? used : pair_chunks;
+    const long long waves = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long c = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < chunks; c += waves) {
+        if (lane < (int)pair_fill[c]) {
+            const unsigned long long e = pair_list[c * 64 + lane];
+            const int64_t p = (int64_t)(e >> 32), spectrum = (int64_t)(e & 0xffffffffull);
+            // everything the pair needs, in one round of loads
+            double sp[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) sp[k] = sc[k * S + spectrum];
+            const double px = (double)x[p], py = (double)y[p], pz = (double)z[p];
+            const double vy_p = (double)vy[p], frac_p = (double)frac[p];
+            const long long idx_p = index ? (long long)index[p] - K.index_shift : p + K.row_base;
+            los_pair(K, sp, spectrum, p, px, py, pz, vy_p, frac_p, idx_p, lad, lds_sums ? racc : radiance,
+                     lds_sums ? nacc : npackets, included, used_cap, used_pairs, n_used, rs_1e6, my_pairs,
+                     my_nonfinite);
+        }
+    }
+    if (lds_sums) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < S; k += blockDim.x) {
+            if (nacc[k]) atomicAdd(&npackets[k], nacc[k]);
+            if (racc[k] != 0.0) unsafeAtomicAdd(&radiance[k], racc[k]);
+        }
+    }
     flush_counter(&ctr->samples_binned, my_pairs);
     flush_counter(&ctr->nonfinite, my_nonfinite);
 }
