@@ -1048,7 +1048,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     const size_t stage_bytes = blob.size();
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
     // ... | per-wave candidate queues
-    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * 8 * sizeof(double) +
+    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * NXC_LOS_SP * sizeof(double) +
                        (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 16;   // + the trip counter
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 

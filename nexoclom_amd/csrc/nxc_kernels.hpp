@@ -1152,7 +1152,8 @@ struct LosK {
     LutDesc line[4];
 };
 
-constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile, all of them in LDS (8 doubles each)
+constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile, all of them in LDS
+constexpr int NXC_LOS_SP = 7;      // doubles per spectrum there: position, boresight, cut-off
 #ifndef NXC_LOS_BLOCK_N             // (overridable: tools/ experiments)
 #define NXC_LOS_BLOCK_N 8
 #endif
@@ -1358,6 +1359,21 @@ NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy
 // K.cull = 0 (boresights that are not unit vectors) gives every block an infinite radius.
 constexpr int NXC_LOS_FORM = 256;        // rows whose packet ids are examined at a time: 4 per lane
 
+// Partner values inside groups of 4 and 8 lanes without going through the LDS crossbar (`__shfl_xor`
+// is a ds_bpermute): data-parallel-primitive moves.  quad_xor1 / quad_xor2 pair the lanes of a
+// quad; oct_other hands a lane a value from the OTHER quad of its group of eight (for values that
+// are already uniform across each quad, e.g. after the two quad steps of a min / max reduction).
+template <int CTRL>
+NXC_DEV double dpp_move(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+NXC_DEV double quad_xor1(double v) { return dpp_move<0xB1>(v); }      // quad_perm [1,0,3,2]
+NXC_DEV double quad_xor2(double v) { return dpp_move<0x4E>(v); }      // quad_perm [2,3,0,1]
+NXC_DEV double oct_other(double v) { return dpp_move<0x141>(v); }     // row_half_mirror: lane i <-> 7 - i
+
 // The placement scan.  A lane's blocks move the write position like pos -> pos + a (no fresh
 // group among them) or pos -> roundup8(pos + a) + c (a blocks, then a fresh group, then c more
 // slots with the later round-ups resolved: they start from a multiple of 8).  Composition is
@@ -1558,16 +1574,19 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     const int64_t s0 = (int64_t)blockIdx.y * NXC_LOS_TILE;
     const int ns = (int)((S - s0) < NXC_LOS_TILE ? (S - s0) : NXC_LOS_TILE);
     double *tile = reinterpret_cast<double *>(nxc_lds + K.tile_off);
-    for (int w = threadIdx.x; w < ns * 8; w += blockDim.x) {
+    // seven doubles per spectrum (the eighth, the ladder length, is only read where a pair is
+    // decided): a stride of 14 banks, so the 32 different spectra a wave instruction of the
+    // pair stages reads lie in different banks (with a stride of 16 they fell on four)
+    for (int w = threadIdx.x; w < ns * NXC_LOS_SP; w += blockDim.x) {
         const int c = w / ns, j = w - c * ns;
-        tile[j * 8 + c] = sc[c * S + s0 + j];
+        tile[j * NXC_LOS_SP + c] = sc[c * S + s0 + j];
     }
     __syncthreads();
     const double rs_1e6 = nxc_recip_seed(1e6);
     unsigned long long my_pairs = 0, my_nonfinite = 0;
     unsigned long long wave_tests = 0;     // sphere tests of this wave (wave-uniform: scalar adds)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int qoff = (int)K.tile_off + NXC_LOS_TILE * 64 + wid * NXC_LOS_WAVE_BYTES;
+    const int qoff = (int)K.tile_off + NXC_LOS_TILE * NXC_LOS_SP * 8 + wid * NXC_LOS_WAVE_BYTES;
     double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
     double *const hsph = sph + 64 * 4;
     double *const gsph = hsph + 16 * 4;
@@ -1596,7 +1615,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             bool hit = false;
             if (s_ < qn) {
                 px = (double)x[p]; py = (double)y[p]; pz = (double)z[p];
-                hit = los_pair_maybe(K, tile + qj * 8, px, py, pz);
+                hit = los_pair_maybe(K, tile + qj * NXC_LOS_SP, px, py, pz);
             }
             const unsigned long long m = __ballot(hit);
             if (m == 0) continue;
@@ -1614,7 +1633,11 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                         (unsigned long long)p << 32 | (unsigned long long)(s0 + qj);
                 cur_fill += n;
             } else if (hit) {
-                los_pair(K, tile + qj * 8, s0 + qj, p, px, py, pz, (double)vy[p], (double)frac[p],
+                double sp8[8];
+#pragma unroll
+                for (int c = 0; c < NXC_LOS_SP; c++) sp8[c] = tile[qj * NXC_LOS_SP + c];
+                sp8[7] = sc[7 * S + s0 + qj];
+                los_pair(K, sp8, s0 + qj, p, px, py, pz, (double)vy[p], (double)frac[p],
                          index ? (long long)index[p] - K.index_shift : p + K.row_base, ladder, radiance,
                          npackets, included, used_cap, used_pairs, n_used, rs_1e6, my_pairs, my_nonfinite);
             }
@@ -1627,7 +1650,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     // (the counter lives in the dynamic block, behind the last wave's lists: the kernels address
     // LDS from its start, so nothing static may sit in front)
     unsigned *const wg_next = reinterpret_cast<unsigned *>(
-        nxc_lds + K.tile_off + NXC_LOS_TILE * 64 + (blockDim.x >> 6) * NXC_LOS_WAVE_BYTES);
+        nxc_lds + K.tile_off + NXC_LOS_TILE * NXC_LOS_SP * 8 + (blockDim.x >> 6) * NXC_LOS_WAVE_BYTES);
     if (threadIdx.x == 0) *wg_next = 0;
     __syncthreads();
     for (;;) {
@@ -1651,30 +1674,31 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
         const double big = 1.7976931348623157e308;
         double blx = has ? cx : big, bhx = has ? cx : -big, bly = has ? cy : big, bhy = has ? cy : -big,
                blz = has ? cz : big, bhz = has ? cz : -big;
-        auto widen = [&](int off) {
-            blx = __builtin_fmin(blx, __shfl_xor(blx, off, 64)); bhx = __builtin_fmax(bhx, __shfl_xor(bhx, off, 64));
-            bly = __builtin_fmin(bly, __shfl_xor(bly, off, 64)); bhy = __builtin_fmax(bhy, __shfl_xor(bhy, off, 64));
-            blz = __builtin_fmin(blz, __shfl_xor(blz, off, 64)); bhz = __builtin_fmax(bhz, __shfl_xor(bhz, off, 64));
+        auto widen = [&](double (*other)(double)) {
+            blx = __builtin_fmin(blx, other(blx)); bhx = __builtin_fmax(bhx, other(bhx));
+            bly = __builtin_fmin(bly, other(bly)); bhy = __builtin_fmax(bhy, other(bhy));
+            blz = __builtin_fmin(blz, other(blz)); bhz = __builtin_fmax(bhz, other(bhz));
         };
         auto reach = [&](double ox, double oy, double oz) {     // from (ox, oy, oz) to my block's far side
             if (!has) return -1.0;
             const double ex = cx - ox, ey = cy - oy, ez = cz - oz;
             return (__builtin_sqrt((ex * ex + ey * ey) + ez * ez) + R) * (1.0 + 1e-12);
         };
-        widen(1); widen(2);
+        widen(quad_xor1); widen(quad_xor2);                     // uniform across each quad now
         const double hx_ = 0.5 * (blx + bhx), hy_ = 0.5 * (bly + bhy), hz_ = 0.5 * (blz + bhz);
         double HR = reach(hx_, hy_, hz_);
-        HR = __builtin_fmax(HR, __shfl_xor(HR, 1, 64));
-        HR = __builtin_fmax(HR, __shfl_xor(HR, 2, 64));
+        HR = __builtin_fmax(HR, quad_xor1(HR));
+        HR = __builtin_fmax(HR, quad_xor2(HR));
         if ((lane & 3) == 0) {
             double *q = hsph + 4 * (lane >> 2);
             q[0] = hx_; q[1] = hy_; q[2] = hz_; q[3] = HR;
         }
-        widen(4);
+        widen(oct_other);                                       // both quads of the group of eight
         const double gx_ = 0.5 * (blx + bhx), gy_ = 0.5 * (bly + bhy), gz_ = 0.5 * (blz + bhz);
         double GR = reach(gx_, gy_, gz_);
-#pragma unroll
-        for (int off = 1; off < 8; off <<= 1) GR = __builtin_fmax(GR, __shfl_xor(GR, off, 64));
+        GR = __builtin_fmax(GR, quad_xor1(GR));
+        GR = __builtin_fmax(GR, quad_xor2(GR));
+        GR = __builtin_fmax(GR, oct_other(GR));
         // the eight group spheres: in LDS, read back with a wave-uniform address (a broadcast;
         // as 64 scalar registers they spilled)
         if ((lane & 7) == 0) {
@@ -1693,9 +1717,9 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
 #endif
         for (int c0 = 0; c0 < ns; c0 += 64) {
             const int jm = c0 + lane;
-            double spj[8];
+            double spj[NXC_LOS_SP];
 #pragma unroll
-            for (int c = 0; c < 8; c++) spj[c] = tile[(jm < ns ? jm : 0) * 8 + c];
+            for (int c = 0; c < NXC_LOS_SP; c++) spj[c] = tile[(jm < ns ? jm : 0) * NXC_LOS_SP + c];
             int npair = 0;
             // the eight tests first (independent chains the scheduler can interleave), then the
             // eight compactions
@@ -1727,7 +1751,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                     const int hs = (int)(e >> 9) * 2 + (lane & 1);
                     const int j = (int)(e & 511u);
                     const double *q = hsph + 4 * hs;
-                    hit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
+                    hit = los_sphere_hits(tile + j * NXC_LOS_SP, q[0], q[1], q[2], q[3], K.tan_dphi);
                     e2 = (unsigned)hs << 9 | (unsigned)j;
                 }
                 wave_tests += 2 * (npair - at0 < 32 ? npair - at0 : 32);
@@ -1746,7 +1770,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                         slot = (int)(e >> 9) * 4 + (lane & 3);
                         j = (int)(e & 511u);
                         const double *q = sph + 4 * slot;
-                        bhit = los_sphere_hits(tile + j * 8, q[0], q[1], q[2], q[3], K.tan_dphi);
+                        bhit = los_sphere_hits(tile + j * NXC_LOS_SP, q[0], q[1], q[2], q[3], K.tan_dphi);
                     }
                     wave_tests += 4 * (n2 - b0 < 16 ? n2 - b0 : 16);
                     // (one block test in 80 passes: its descriptor comes from memory then)
