@@ -1493,10 +1493,24 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
     // the last group is completed with empty slots
     const int tail = (int)los_place_apply(all, 0);
     const int full = (tail + 7) & ~7;
+    // The blocks change hands: a lane found the blocks that START in its four rows (none, one,
+    // rarely more), but the spheres are computed one block per lane -- the descriptors go through
+    // LDS by slot number, empty slots stay zero.
+    __shared__ unsigned long long slot_desc[NXC_LOS_BLOCKS_THREADS / 64][NXC_LOS_FORM + 8];
+    const int wid = threadIdx.x >> 6;
+    unsigned long long *const mine_desc = slot_desc[wid];
+    for (int s_ = lane; s_ < full; s_ += 64) mine_desc[s_] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (!emit[k]) continue;
+        if (fresh[k]) pos = (pos + 7) & ~7;
+        mine_desc[pos++] = d[k];
+    }
     // one returning atomic per WORKGROUP (a single address takes about 80 million a second: one
     // per region would cost half a millisecond for 1e7 rows)
     __shared__ long long wg_base[NXC_LOS_BLOCKS_THREADS / 64 + 1];
-    const int wid = threadIdx.x >> 6;
     if (lane == 0) wg_base[wid + 1] = full;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1506,36 +1520,31 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
     }
     __syncthreads();
     stream0 = wg_base[0] + wg_base[wid + 1];
-    if (tail + lane < full) put(tail + lane, 0ull, 0.0, 0.0, 0.0, -1.0);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (!emit[k]) continue;
-        if (fresh[k]) {
-            const int up = (pos + 7) & ~7;
-            for (; pos < up; pos++) put(pos, 0ull, 0.0, 0.0, 0.0, -1.0);         // slots left empty
-        }
-        const int64_t p0 = (int64_t)(d[k] >> 4);
-        const int nb = (int)(d[k] & 15ull);
+    for (int s_ = lane; s_ < full; s_ += 64) {
+        const unsigned long long desc = mine_desc[s_];
+        if (desc == 0ull) { put(s_, 0ull, 0.0, 0.0, 0.0, -1.0); continue; }   // a slot left empty
+        const int64_t p0 = (int64_t)(desc >> 4);
+        const int nb = (int)(desc & 15ull);
         // bounding sphere: centre of the bounding box, largest distance from it
         double px[NXC_LOS_BLOCK], py[NXC_LOS_BLOCK], pz[NXC_LOS_BLOCK];
 #pragma unroll
-        for (int s_ = 0; s_ < NXC_LOS_BLOCK; s_++) {
-            const int64_t p = p0 + (s_ < nb ? s_ : 0);       // all the loads in flight together
-            px[s_] = (double)x[p]; py[s_] = (double)y[p]; pz[s_] = (double)z[p];
+        for (int r = 0; r < NXC_LOS_BLOCK; r++) {
+            const int64_t p = p0 + (r < nb ? r : 0);         // all the loads in flight together
+            px[r] = (double)x[p]; py[r] = (double)y[p]; pz[r] = (double)z[p];
         }
         double lox = px[0], hix = lox, loy = py[0], hiy = loy, loz = pz[0], hiz = loz;
 #pragma unroll
-        for (int s_ = 1; s_ < NXC_LOS_BLOCK; s_++) {
-            lox = __builtin_fmin(lox, px[s_]); hix = __builtin_fmax(hix, px[s_]);
-            loy = __builtin_fmin(loy, py[s_]); hiy = __builtin_fmax(hiy, py[s_]);
-            loz = __builtin_fmin(loz, pz[s_]); hiz = __builtin_fmax(hiz, pz[s_]);
+        for (int r = 1; r < NXC_LOS_BLOCK; r++) {
+            lox = __builtin_fmin(lox, px[r]); hix = __builtin_fmax(hix, px[r]);
+            loy = __builtin_fmin(loy, py[r]); hiy = __builtin_fmax(hiy, py[r]);
+            loz = __builtin_fmin(loz, pz[r]); hiz = __builtin_fmax(hiz, pz[r]);
         }
         double cx = 0.5 * (lox + hix), cy = 0.5 * (loy + hiy), cz = 0.5 * (loz + hiz);
         double R2 = 0.0;
         bool nan_seen = false;
 #pragma unroll
-        for (int s_ = 0; s_ < NXC_LOS_BLOCK; s_++) {
-            const double ex = px[s_] - cx, ey = py[s_] - cy, ez = pz[s_] - cz;
+        for (int r = 0; r < NXC_LOS_BLOCK; r++) {
+            const double ex = px[r] - cx, ey = py[r] - cy, ez = pz[r] - cz;
             const double e2 = (ex * ex + ey * ey) + ez * ez;
             nan_seen = nan_seen || e2 != e2;   // (fmin / fmax drop a NaN: the box alone would not show it)
             R2 = __builtin_fmax(R2, e2);
@@ -1544,8 +1553,7 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
         const bool finite = !nan_seen && (R2 <= 1.7976931348623157e308) && (cx == cx) && (cy == cy) && (cz == cz);
         double R = __builtin_sqrt(R2) * (1.0 + 1e-12);
         if (!finite || !cull) { cx = cy = cz = 0.0; R = __builtin_inf(); }
-        put(pos, d[k], cx, cy, cz, R);
-        pos++;
+        put(s_, desc, cx, cy, cz, R);
     }
 }
 

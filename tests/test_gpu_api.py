@@ -216,12 +216,12 @@ def test_los_cones_match_oracle(ctx):
 
 
 def test_los_used_pairs_and_tiles(ctx):
-    """More spectra than one LDS tile (128), small cone, and the (spectrum, sample) pair list."""
+    """More spectra than one LDS tile (512), small cone, and the (spectrum, sample) pair list."""
     from nexoclom_amd import LOSResult, SpacecraftData
     inputs = Input(os.path.join(PKG_INPUTS, 'Na.mercury.bench.input'))
     inputs.options.endtime = type(inputs.options.endtime)(6000., 's')
     inputs.run(3000, seed=5, context=ctx)
-    pos, look = _orbit(300, seed=3)
+    pos, look = _orbit(700, seed=3)
     sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
     dphi = np.radians(1.0)
     los = LOSResult(sc, inputs, dphi=dphi, context=ctx)
@@ -246,6 +246,7 @@ def test_los_used_pairs_and_tiles(ctx):
     r, n, inc, used = O.los_iteration(smp, scd, dphi, 25., float(out.vrplanet)/out.unit_km,
                                       los.g_tables(float(out.aplanet)), out.unit_km*1e5,
                                       n_index=3000)
+    assert (n[512:] > 0).sum() > 20                # the second tile of spectra sees packets too
     assert np.array_equal(it['npackets'].values, n)
     np.testing.assert_allclose(it['radiance'].values, r, rtol=1e-10, atol=0)
     pairs = set(zip(it['used'][0].tolist(), it['used'][1].tolist()))
