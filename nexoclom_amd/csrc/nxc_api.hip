@@ -348,6 +348,7 @@ struct nxc_handle {
     size_t queue_cap = 0;
     size_t order_cap = 0;
     bool have_order = false;
+    int order_key = 0;               // what the queue is sorted by: 0 |v|^2, 1 known lifetimes, 2 the adaptive driver's key
     int64_t first_id = 0;            // global index of resident packet 0 (RNG counter space)
     bool have_bounce = false;
     double *d_bounce = nullptr;      // spline knots + coefficients of the accommodation table
@@ -400,7 +401,7 @@ struct nxc_handle {
 };
 
 static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifetimes,
-                           int64_t max_steps);
+                           int64_t max_steps, bool flight_key = false);
 
 namespace {
 
@@ -797,6 +798,14 @@ int pick_fused(nxc_handle *h, size_t tables, size_t lds, int64_t n_iter, double 
     if (h->have_bounce) return NXC_FUSED(true, false);
     return full ? NXC_FUSED(false, true) : NXC_FUSED(false, false);
 #undef NXC_FUSED
+}
+
+// The constant-step kernels want the fastest (longest-lived) packets first: a resident set that the
+// adaptive driver has re-sorted for itself goes back to that order.
+int speed_order_for_const(nxc_handle *h)
+{
+    if (h->order_key != 2 || h->n_packets < 2) return NXC_OK;
+    return order_on_device(h, -1.0, nullptr, 0);
 }
 
 int launch_const(nxc_handle *h, double step, int64_t n_iter, double outeredge, bool image,
@@ -1859,7 +1868,7 @@ int nxc_rk5_step(nxc_handle *h, int64_t n, const double *soa_in, const double *h
 static int order_async(nxc_handle *h, hipStream_t st, const double *soa, int64_t stride, int64_t n,
                        const long long *d_lifetimes, double scale, unsigned long long *d_max,
                        unsigned long long *d_hist, unsigned *out_order, double *out_queue,
-                       bool beside_persistent, unsigned base = 0)
+                       bool beside_persistent, unsigned base = 0, bool flight_key = false)
 {
     const size_t hb = (size_t)NXC_ORDER_BINS * sizeof(unsigned long long);
     const int grid = flat_grid(h, n, NXC_BLOCK);
@@ -1868,14 +1877,16 @@ static int order_async(nxc_handle *h, hipStream_t st, const double *soa, int64_t
 #define NXC_ORDER_LAUNCH(KERNEL, ...)                                                           \
     hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(NXC_BLOCK), 0, st, soa, d_lifetimes, stride, n,  \
                        scale, mx, __VA_ARGS__)
-    if (d_lifetimes) NXC_ORDER_LAUNCH((k_order_hist<true, true>), d_hist);
-    else if (beside_persistent) NXC_ORDER_LAUNCH((k_order_hist<false, false>), d_hist);
-    else NXC_ORDER_LAUNCH((k_order_hist<false, true>), d_hist);
+    if (d_lifetimes) NXC_ORDER_LAUNCH((k_order_hist<1, true>), d_hist);
+    else if (flight_key) NXC_ORDER_LAUNCH((k_order_hist<2, true>), d_hist);
+    else if (beside_persistent) NXC_ORDER_LAUNCH((k_order_hist<0, false>), d_hist);
+    else NXC_ORDER_LAUNCH((k_order_hist<0, true>), d_hist);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(64), 0, st, d_hist);
     HIPCHK(hipGetLastError());
-    if (d_lifetimes) NXC_ORDER_LAUNCH(k_order_scatter<true>, d_hist, out_order, base, out_queue);
-    else NXC_ORDER_LAUNCH(k_order_scatter<false>, d_hist, out_order, base, out_queue);
+    if (d_lifetimes) NXC_ORDER_LAUNCH(k_order_scatter<1>, d_hist, out_order, base, out_queue);
+    else if (flight_key) NXC_ORDER_LAUNCH(k_order_scatter<2>, d_hist, out_order, base, out_queue);
+    else NXC_ORDER_LAUNCH(k_order_scatter<0>, d_hist, out_order, base, out_queue);
 #undef NXC_ORDER_LAUNCH
     HIPCHK(hipGetLastError());
     return NXC_OK;
@@ -1886,10 +1897,11 @@ static int order_async(nxc_handle *h, hipStream_t st, const double *soa, int64_t
 // sort by those step counts instead (exact lifetimes from a counting pass; max_steps = their
 // upper bound).
 static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifetimes,
-                           int64_t max_steps)
+                           int64_t max_steps, bool flight_key)
 {
     const int64_t n = h->n_packets;
     const bool by_steps = d_lifetimes != nullptr;
+    h->order_key = by_steps ? 1 : flight_key ? 2 : 0;
     if (by_steps) {
         if (n < 2 || n >= (int64_t)0xffffffffll || max_steps < 1) return NXC_OK;   // keep what there is
     } else {
@@ -1910,13 +1922,17 @@ static int order_on_device(nxc_handle *h, double k2max, const long long *d_lifet
                             : (k2max > 0 ? (double)(NXC_ORDER_BINS - 1) / k2max : 0.0);
     if (!by_steps && !(k2max > 0)) {
         HIPCHK(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
-                           h->stream, (const double *)h->d_packets, n, n, d_max);
+        if (flight_key)
+            hipLaunchKernelGGL(k_speed_max<true>, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+                               h->stream, (const double *)h->d_packets, n, n, d_max);
+        else
+            hipLaunchKernelGGL(k_speed_max<false>, dim3(flat_grid(h, n, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+                               h->stream, (const double *)h->d_packets, n, n, d_max);
         HIPCHK(hipGetLastError());
     }
     h->have_order = false;
     if ((rc = order_async(h, h->stream, h->d_packets, n, n, d_lifetimes, scale, d_max, h->d_hist,
-                          h->d_order, h->d_queue, false)))
+                          h->d_order, h->d_queue, false, 0, flight_key)))
         return rc;
     HIPCHK(stream_sync(h));
     h->have_order = true;
@@ -2123,6 +2139,7 @@ int nxc_integrate_const_async(nxc_handle *h, double step, int64_t n_iter, double
     if (!(step > 0) || n_iter < 0) return fail(NXC_ERR_ARG, "step must be > 0, n_iter >= 0");
     const bool image = (flags & NXC_RUN_IMAGE) != 0;
     if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
+    if ((rc = speed_order_for_const(h))) return rc;
     return launch_const(h, step, n_iter, outeredge, image, nullptr, nullptr);
     });
 }
@@ -2214,7 +2231,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, sizeof(unsigned long long), h->stream2);
         if (e != hipSuccess)
             return give_up(fail_hip("streamed upload", e));
-        hipLaunchKernelGGL(k_speed_max, dim3(flat_grid(h, len, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
+        hipLaunchKernelGGL(k_speed_max<false>, dim3(flat_grid(h, len, NXC_BLOCK)), dim3(NXC_BLOCK), 0,
                            h->stream2, (const double *)(h->d_packets + p0), n, len, d_max);
         if ((rc = order_async(h, h->stream2, h->d_packets + p0, n, len, nullptr, 0.0, d_max, hist,
                               h->d_order + p0, h->d_queue + 8 * p0, true, (unsigned)p0)))
@@ -2224,6 +2241,7 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
         if (hipGetLastError() != hipSuccess) return give_up(fail(NXC_ERR_HIP, "streamed upload: launch failed"));
     }
     h->have_order = true;            // pieces sorted one by one: still a valid queue order
+    h->order_key = 0;
     h->streamed_pending = true;
     // the handle's stream continues after the ordering stream as well
     HIPCHK(hipEventRecord(h->ev_piece[32], h->stream2));
@@ -2245,6 +2263,7 @@ int nxc_integrate_const(nxc_handle *h, double step, int64_t n_iter, double outer
     const bool image = (flags & NXC_RUN_IMAGE) != 0;
     if (image && !h->have_image) return fail(NXC_ERR_STATE, "NXC_RUN_IMAGE without nxc_set_image");
     if (traj_out && nrec < n_iter + 1) return fail(NXC_ERR_ARG, "nrec must be >= n_iter + 1");
+    if ((rc = speed_order_for_const(h))) return rc;
 
     const size_t col = (size_t)n * sizeof(double);
     double *d_final = nullptr;
@@ -2330,6 +2349,7 @@ int nxc_integrate_const_rows(nxc_handle *h, double step, int64_t n_iter, double 
     if (rc) return rc;
     if (h->n_packets < 1) return fail(NXC_ERR_STATE, "no resident packets (nxc_packets_upload)");
     if (!(step > 0) || n_iter < 0 || !total_out) return fail(NXC_ERR_ARG, "bad arguments");
+    if ((rc = speed_order_for_const(h))) return rc;
     long long total = 0;
     if ((rc = count_rows(h, step, n_iter, outeredge, false, lengths_out, &total))) return rc;
     *total_out = total;
@@ -2471,6 +2491,9 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     if ((rc = ensure(reinterpret_cast<void **>(&h->d_scratch), &h->scratch_cap, 9 * col)))
         return rc;
     double *d_final = h->d_scratch, *d_hs = d_final + 8 * n;
+    // the adaptive driver's queue: slow packets with much time left first (nxc_kernels.hpp:
+    // flight_key); once per resident set
+    if (h->order_key != 2 && (rc = order_on_device(h, -1.0, nullptr, 0, true))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     int grid = 1, block = BLOCK_PERSIST;
     const size_t lds = persist_lds(h->force_bytes);

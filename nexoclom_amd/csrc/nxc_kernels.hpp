@@ -2081,8 +2081,36 @@ NXC_DEV int speed_bin(const double *__restrict__ soa, int64_t stride, int64_t i,
     return NXC_ORDER_BINS - 1 - b;
 }
 
+// The queue key of the ADAPTIVE driver: remaining time over launch speed, descending.  A packet's
+// attempts run one after the other in one lane, so the launch lasts at least as long as its
+// longest chain, and the long chains belong to SLOW packets with much time left (bound packets
+// that keep a small step for the rest of their flight), not to the fast ones: measured on 1e5
+// packets of the bench workload (tests/tools/var_schedule.py), the lane-refill schedule's makespan
+// is 6965 attempts for fastest-first, 5791 as sampled, 5069 for this key and 5017 for
+// longest-first, which needs the answer (at 50 packets per lane: 27 818 / 26 482 / 24 863 against
+// a mean load of 24 319).
+NXC_DEV double flight_key(const double *__restrict__ soa, int64_t stride, int64_t i)
+{
+    const double vx = soa[4 * stride + i], vy = soa[5 * stride + i], vz = soa[6 * stride + i];
+    return soa[i] / __builtin_sqrt(vx * vx + vy * vy + vz * vz);
+}
+NXC_DEV int flight_bin(const double *__restrict__ soa, int64_t stride, int64_t i, double scale)
+{
+    const double f = flight_key(soa, stride, i) * scale;       // NaN (0 / 0) goes last, +inf first
+    int b = (f >= 0.0 && f < (double)NXC_ORDER_BINS) ? (int)f : (f >= (double)NXC_ORDER_BINS ? NXC_ORDER_BINS - 1 : 0);
+    return NXC_ORDER_BINS - 1 - b;
+}
+// KEY: 0 = |v|^2, 1 = known step counts, 2 = the adaptive driver's flight key
+template <int KEY>
+NXC_DEV int order_bin(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
+                      int64_t i, double scale)
+{
+    return KEY == 1 ? steps_bin(steps, i, scale) : KEY == 2 ? flight_bin(soa, stride, i, scale)
+                                                              : speed_bin(soa, stride, i, scale);
+}
+
 // The bin scale: given by the host, or (max_bits != null) derived on the device from the largest
-// |v|^2 that k_speed_max left there, so that a piece can be ordered without a host round trip.
+// key that k_speed_max left there, so that a piece can be ordered without a host round trip.
 NXC_DEV double order_scale(double scale, const unsigned long long *__restrict__ max_bits)
 {
     if (!max_bits) return scale;
@@ -2092,6 +2120,7 @@ NXC_DEV double order_scale(double scale, const unsigned long long *__restrict__ 
 
 // Largest finite |v|^2 of the packets (bit pattern of a non-negative double: its order as an
 // unsigned integer is its order as a number).
+template <bool FLIGHT = false>      // FLIGHT: the largest finite flight key instead
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_speed_max(const double *__restrict__ soa, int64_t stride, int64_t n, unsigned long long *__restrict__ out)
 {
@@ -2099,7 +2128,7 @@ k_speed_max(const double *__restrict__ soa, int64_t stride, int64_t n, unsigned 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const double vx = soa[4 * stride + i], vy = soa[5 * stride + i], vz = soa[6 * stride + i];
-        const double f = vx * vx + vy * vy + vz * vz;
+        const double f = FLIGHT ? flight_key(soa, stride, i) : vx * vx + vy * vy + vz * vz;
         if (f <= 1.7976931348623157e308 && f > m) m = f;
     }
 #pragma unroll
@@ -2113,7 +2142,7 @@ k_speed_max(const double *__restrict__ soa, int64_t stride, int64_t n, unsigned 
 
 // LDS: privatised bins (the launches that order a whole resident set); !LDS: straight global
 // atomics, for the launches that run BESIDE a persistent kernel whose block leaves no LDS free.
-template <bool BY_STEPS, bool LDS>
+template <int KEY, bool LDS>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_order_hist(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
              int64_t n, double scale_, const unsigned long long *__restrict__ max_bits,
@@ -2126,14 +2155,14 @@ k_order_hist(const double *__restrict__ soa, const long long *__restrict__ steps
         __syncthreads();
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            atomicAdd(&lh[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1u);
+            atomicAdd(&lh[order_bin<KEY>(soa, steps, stride, i, scale)], 1u);
         __syncthreads();
         for (int b = threadIdx.x; b < NXC_ORDER_BINS; b += blockDim.x)
             if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
     } else {
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
              i += (int64_t)gridDim.x * blockDim.x)
-            atomicAdd(&hist[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1ull);
+            atomicAdd(&hist[order_bin<KEY>(soa, steps, stride, i, scale)], 1ull);
     }
 }
 
@@ -2161,7 +2190,7 @@ k_order_scan(unsigned long long *__restrict__ hist)
     }
 }
 
-template <bool BY_STEPS>
+template <int KEY>
 __global__ void __launch_bounds__(NXC_BLOCK)
 k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ steps, int64_t stride,
                 int64_t n, double scale_, const unsigned long long *__restrict__ max_bits,
@@ -2180,7 +2209,7 @@ k_order_scatter(const double *__restrict__ soa, const long long *__restrict__ st
 #pragma unroll
         for (int c = 0; c < 8; c++) v[c] = soa[c * stride + i];
         const unsigned long long pos =
-            atomicAdd(&cursor[BY_STEPS ? steps_bin(steps, i, scale) : speed_bin(soa, stride, i, scale)], 1ull);
+            atomicAdd(&cursor[order_bin<KEY>(soa, steps, stride, i, scale)], 1ull);
         order[pos] = base + (unsigned)i;
         nxc_v2d *rec = reinterpret_cast<nxc_v2d *>(queue + 8 * pos);
 #pragma unroll
