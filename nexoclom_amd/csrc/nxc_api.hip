@@ -1058,7 +1058,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
     // ... | per-wave candidate queues
     const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * NXC_LOS_SP * sizeof(double) +
-                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 16;   // + the trip counter
+                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 32;   // + trip counter, counter sums
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
     // device scratch: blob | sc | ladder | radiance | npackets | included | used
