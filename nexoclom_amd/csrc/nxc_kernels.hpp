@@ -115,6 +115,31 @@ NXC_DEV void flush_counter(unsigned long long *dst, unsigned long long v)
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 }
 
+// Up to three counters of a whole WORKGROUP: summed in LDS (`lds`: 24 bytes nobody else uses any
+// more; every thread of the block must call), then one atomic each.  Returning or not, atomics on
+// one address -- one cache line -- go through at about 80 million a second, so a launch of 4096
+// waves that each add to two counters as they all finish spends 0.1 ms doing so.
+NXC_DEV void flush_counters_wg(unsigned long long *lds, unsigned long long *d0, unsigned long long v0,
+                               unsigned long long *d1, unsigned long long v1,
+                               unsigned long long *d2, unsigned long long v2)
+{
+    __syncthreads();
+    if (threadIdx.x < 3) lds[threadIdx.x] = 0ull;
+    __syncthreads();
+    v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2);
+    if ((threadIdx.x & 63) == 0) {
+        if (v0) atomicAdd(&lds[0], v0);
+        if (v1) atomicAdd(&lds[1], v1);
+        if (v2) atomicAdd(&lds[2], v2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lds[0]) atomicAdd(d0, lds[0]);
+        if (lds[1]) atomicAdd(d1, lds[1]);
+        if (lds[2]) atomicAdd(d2, lds[2]);
+    }
+}
+
 NXC_DEV long long wave_bcast0(long long v)
 {
     int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
@@ -736,9 +761,9 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
         if (has) { sx = x[i]; sy = y[i]; sz = z[i]; svy = vy[i]; sf = frac[i]; }
         image_sample(lds_header().G, IR, has, sx, sy, sz, svy, sf, acc2, my_binned, my_nonfinite);
     }
-    flush_counter(&ctr->samples, my_samples);
-    flush_counter(&ctr->samples_binned, my_binned);
-    flush_counter(&ctr->nonfinite, my_nonfinite);
+    // (the tables are not read any more: their first bytes carry the workgroup's sums)
+    flush_counters_wg(reinterpret_cast<unsigned long long *>(nxc_lds), &ctr->samples, my_samples,
+                      &ctr->samples_binned, my_binned, &ctr->nonfinite, my_nonfinite);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -945,9 +970,9 @@ k_image_bin(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t
         if (n > 0) flush(b, n);
         if (lane == 0) nlist[(size_t)blockIdx.x * nb + b] = bc[b] << 16 | (unsigned)(n > 0 ? n : CAP);
     }
-    flush_counter(&ctr->samples, my_samples);
-    flush_counter(&ctr->samples_binned, my_binned);
-    flush_counter(&ctr->nonfinite, my_nonfinite);
+    // (the staging blocks are empty now: their first bytes carry the workgroup's sums)
+    flush_counters_wg(reinterpret_cast<unsigned long long *>(stw), &ctr->samples, my_samples,
+                      &ctr->samples_binned, my_binned, &ctr->nonfinite, my_nonfinite);
 }
 
 // Pass 2.  Workgroup (tile b, group g) adds the chunks of tile b written by the producers
@@ -1040,10 +1065,9 @@ k_image_tiles(const unsigned char *__restrict__ blob, int64_t stage_bytes, int n
         const int pix = ((lrow << nb_log2) + b) * nz + iz;
         image_add_pairs_n(has, pix, has ? tw[i] : 0.0, has ? (double)tc[i] : 0.0, acc2);
     }
-    if (WEIGH) {
-        flush_counter(&ctr->samples_binned, my_binned);
-        flush_counter(&ctr->nonfinite, my_nonfinite);
-    }
+    if (WEIGH)      // (the tile has been handed over: its first bytes carry the workgroup's sums)
+        flush_counters_wg(reinterpret_cast<unsigned long long *>(tw), &ctr->samples_binned, my_binned,
+                          &ctr->nonfinite, my_nonfinite, &ctr->nonfinite, 0ull);
 }
 
 // ---- measurement helpers (bench.py's roofline object) --------------------------------------------
@@ -1806,24 +1830,10 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     }
     while (queue.waiting() > 0) drain();
     if (cur_chunk >= 0 && cur_chunk < pair_chunks && lane == 0) pair_fill[cur_chunk] = (unsigned)cur_fill;
-    // the counters: summed over the workgroup in LDS first.  (One atomic per wave and counter --
-    // 8192 on one cache line -- took 0.1 ms at the end of this 0.37 ms kernel.)
-    unsigned long long *const wg_ctr = reinterpret_cast<unsigned long long *>(wg_next + 2);
-    __syncthreads();
-    if (threadIdx.x < 3) wg_ctr[threadIdx.x] = 0ull;
-    __syncthreads();
-    const unsigned long long w_pairs = wave_sum(my_pairs), w_nonf = wave_sum(my_nonfinite);
-    if (lane == 0) {
-        atomicAdd(&wg_ctr[0], wave_tests);
-        if (w_pairs) atomicAdd(&wg_ctr[1], w_pairs);
-        if (w_nonf) atomicAdd(&wg_ctr[2], w_nonf);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (wg_ctr[0]) atomicAdd(&ctr->samples, wg_ctr[0]);
-        if (wg_ctr[1]) atomicAdd(&ctr->samples_binned, wg_ctr[1]);
-        if (wg_ctr[2]) atomicAdd(&ctr->nonfinite, wg_ctr[2]);
-    }
+    // the counters of the workgroup in one go (wave_tests is wave-uniform: lane 0 carries it)
+    flush_counters_wg(reinterpret_cast<unsigned long long *>(wg_next + 2), &ctr->samples,
+                      lane == 0 ? wave_tests : 0ull, &ctr->samples_binned, my_pairs, &ctr->nonfinite,
+                      my_nonfinite);
 }
 
 // The pairs k_los found near a cone, decided and weighed as the reference does it
