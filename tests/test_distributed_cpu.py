@@ -219,10 +219,10 @@ def _worker_two_stage(rank, world, port, tmpdir, kind):
     sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
     npackets, size, passes = 2300, 500, 5                 # 5 Outputs of 500: the last overshoots
 
-    def flow(cp_, ctx):
+    def flow(cp_, ctx, sampler='numpy'):
         inputs = inputs_()
         with contextlib.redirect_stdout(io.StringIO()):
-            inputs.run(npackets, packs_per_it=size, seed=77, context=ctx, cp=cp_)
+            inputs.run(npackets, packs_per_it=size, seed=77, context=ctx, cp=cp_, sampler=sampler)
             image = inputs.produce_image(PARAMS, context=ctx, cp=cp_, reduce='host')
             los = LOSResult(sc, inputs, dphi=np.radians(3.0), context=ctx)
             los.simulate_data_from_inputs(sc, cp=cp_, reduce='host')
@@ -251,6 +251,18 @@ def _worker_two_stage(rank, world, port, tmpdir, kind):
         assert los1.npackets_los.sum() > 100
         assert np.array_equal(los.npackets_los.values, los1.npackets_los.values)
         np.testing.assert_allclose(los.radiance.values, los1.radiance.values, rtol=1e-12, atol=0)
+    # the device sampler is counter-based on the GLOBAL packet index: a rank's Outputs must start at
+    # the index they have in the one-process run (Input.run's `drawn` under sharding)
+    ctx_d = OracleContext()
+    inputs_d, image_d, _ = flow(cp, ctx_d, sampler='device')
+    firsts = [o._first_index for o in inputs_d._catalogue]
+    assert firsts == [size*(lo + k) for k in range(hi - lo)], firsts
+    if rank == 0:
+        alone_d, image_d1, _ = flow(None, OracleContext(), sampler='device')
+        for k, out in enumerate(inputs_d._catalogue):
+            assert np.array_equal(out.X0.values, alone_d._catalogue[lo + k].X0.values)
+        assert np.array_equal(image_d.packet_image, image_d1.packet_image)
+        assert not np.array_equal(image_d.packet_image, image.packet_image)   # other packets than the host's
         open(os.path.join(tmpdir, 'ok'), 'w').write('ok')
     cp.barrier()
     cp.close()
