@@ -22,6 +22,10 @@ DEPS = [os.path.join(HERE, 'csrc', f) for f in
         ('nxc_api.hip', 'nxc_kernels.hpp', 'nxc_device.hpp', 'nxc_math.hpp', 'nxc_log_table.hpp')]
 DEPS.append(os.path.join(os.path.dirname(HERE), 'include', 'nexoclom_hip.h'))
 OUT = os.path.join(HERE, 'lib', 'libnexoclom_hip.so')
+# the same library with NumPy's two roundings per tableau term (rk5.py:33-35,41-43) instead of the
+# fused multiply-adds: not what the package loads -- the yardstick the parity suite keeps alive
+# (tests/test_gpu_two_roundings.py, against the C checker built with -DORACLE_TABLEAU_TWO_ROUNDINGS)
+OUT_TWO_ROUNDINGS = os.path.join(HERE, 'lib', 'libnexoclom_hip_2r.so')
 
 FLAGS = ['-O3', '--offload-arch=gfx950', '-ffp-contract=off', '-fno-fast-math',
          '-munsafe-fp-atomics', '-mllvm', '-disable-machine-licm', '-fPIC', '-shared',
@@ -38,26 +42,39 @@ def hipcc():
     return exe
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
+def up_to_date(out=OUT):
+    if not os.path.exists(out):
         return False
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     return all(os.path.getmtime(d) <= t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [SRC, '-o', OUT, '-ldl']
+def build(force=False, verbose=False, two_roundings=False):
+    out = OUT_TWO_ROUNDINGS if two_roundings else OUT
+    if not force and up_to_date(out):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    extra = ['-DNXC_TABLEAU_TWO_ROUNDINGS'] if two_roundings else []
+    cmd = [hipcc()] + FLAGS + extra + [SRC, '-o', out, '-ldl']
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError('hipcc failed building libnexoclom_hip.so')
-    return OUT
+        raise RuntimeError(f'hipcc failed building {os.path.basename(out)}')
+    return out
+
+
+def build_all(force=False, verbose=False):
+    """Both libraries, side by side (two hipcc processes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:
+        jobs = [pool.submit(build, force, verbose, two) for two in (False, True)]
+        return [j.result() for j in jobs]
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    if '--all' in sys.argv:
+        print('\n'.join(build_all(force='--force' in sys.argv, verbose=True)))
+    else:
+        print(build(force='--force' in sys.argv, verbose=True, two_roundings='--two-roundings' in sys.argv))
