@@ -323,6 +323,40 @@ def test_los_block_formation_follows_any_index_column(ctx, layout):
     np.testing.assert_allclose(res2['radiance'], r2, rtol=1e-10, atol=0)
 
 
+def test_los_with_more_spectra_than_the_lds_sums_hold(ctx):
+    """2800 lines of sight: six LDS tiles of spectra in k_los, and too many for k_los_pairs' per-
+    workgroup sums in LDS (it then adds straight to memory).  Same answers as the restatement."""
+    from nexoclom_amd.LOSResult import POSITION, BORESIGHT, arccos_threshold, los_geometry
+    import pandas as pd
+    rng = np.random.default_rng(12)
+    f = H.mercury_forces('Na', 1.3)
+    lens = rng.integers(5, 60, 600)
+    P = int(lens.sum())
+    ids = np.repeat(np.arange(len(lens)), lens)
+    start = rng.normal(0, 1.8, (len(lens), 3))
+    vel = rng.normal(0, 0.03, (len(lens), 3))
+    k = np.arange(P) - np.repeat(np.cumsum(lens) - lens, lens)
+    pts = start[ids] + vel[ids]*k[:, None]
+    vy, frac = rng.normal(0, 2e-3, P), rng.uniform(0.05, 1, P)
+    S = 2800
+    pos, look = _orbit(S, seed=4)
+    dphi = np.radians(1.5)
+    spectra = pd.DataFrame(dict(zip(POSITION + BORESIGHT, list(pos.T) + list(look.T))))
+    cut, lengths, ladder = los_geometry(spectra, 25., dphi)
+    sc = np.vstack([pos.T, look.T, cut, lengths.astype(float)])
+    gt = H.g_tables('Na', f.aplanet, f.R_km, (5891, 5897))
+    cols = [np.ascontiguousarray(c) for c in (pts[:, 0], pts[:, 1], pts[:, 2], vy, frac)]
+    res = ctx.los_accumulate(dphi, np.sin(dphi), np.sin(2*dphi), arccos_threshold(dphi), f.vrplanet,
+                             f.R_km*1e5, gt, ladder, sc, *cols, index=ids.astype(np.int64),
+                             n_index=len(lens))
+    smp = dict(x=cols[0], y=cols[1], z=cols[2], vy=vy, frac=frac, Index=ids)
+    scd = {c: spectra[c].values for c in spectra.columns}
+    r, n, inc, _ = O.los_iteration(smp, scd, dphi, 25., f.vrplanet, gt, f.R_km*1e5, n_index=len(lens))
+    assert n.sum() > 1000 and (n[2560:] > 0).sum() > 10          # the last tile sees packets too
+    assert np.array_equal(res['npackets'], n) and np.array_equal(res['included'], inc)
+    np.testing.assert_allclose(res['radiance'], r, rtol=1e-10, atol=0)
+
+
 def test_device_sampler_matches_philox_oracle_and_reference_statistics(ctx):
     """f-4: k_sample == NumPy Philox restatement (to libm rounding), is counter-addressed
     (chunks concatenate), and is statistically the reference's source (KS tests in the spirit of
