@@ -1057,8 +1057,13 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     const size_t stage_bytes = blob.size();
     K.tile_off = (int64_t)((stage_bytes + 31) & ~size_t(31));
     // ... | per-wave candidate queues
-    const size_t lds = (size_t)K.tile_off + (size_t)NXC_LOS_TILE * NXC_LOS_SP * sizeof(double) +
-                       (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 32;   // + trip counter, counter sums
+    // all the spectra of a launch in LDS, 512 at a time -- fewer when the g-value tables are large
+    // (four lines of 389 points: 66 KB) and leave less room beside the per-wave lists
+    const size_t lds_rest = (size_t)K.tile_off + (size_t)(NXC_LOS_THREADS / 64) * NXC_LOS_WAVE_BYTES + 32;
+    K.tile_cap = NXC_LOS_TILE;
+    while (K.tile_cap > 32 && lds_rest + (size_t)K.tile_cap * NXC_LOS_SP * sizeof(double) > 160 * 1024)
+        K.tile_cap >>= 1;
+    const size_t lds = lds_rest + (size_t)K.tile_cap * NXC_LOS_SP * sizeof(double);   // (+ trip counter, counter sums)
     if (lds > 160 * 1024) return fail(NXC_ERR_ARG, "g-value tables exceed the LDS");
 
     // device scratch: blob | sc | ladder | radiance | npackets | included | used
@@ -1083,7 +1088,7 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), st));
     if (P > 0) {
         if ((rc = prep_kernel(k_los<T, I>, lds))) return rc;
-        const int tiles = (int)((S + NXC_LOS_TILE - 1) / NXC_LOS_TILE);
+        const int tiles = (int)((S + K.tile_cap - 1) / K.tile_cap);
         constexpr int WPG = NXC_LOS_THREADS / 64;                  // waves per workgroup of k_los
         // the samples go through in slabs: the block scratch is sized for the worst case of one
         // slot per row (40 bytes; the bench cloud uses a fifth of a slot per row)

@@ -1168,7 +1168,8 @@ struct LosK {
     double sin_dphi, sin_2dphi, cos_thr, cos_thr2_lo, vrplanet, unit_cm2;
     double log1p_s_inv, t0;        // ladder: t_k = t0 (1 + sin_dphi)^k; only to seed the ball search
     double tan_dphi;               // block culling: a cone's radius per unit distance along its axis
-    int cull, pad_;                // 1: every boresight is a unit vector (checked on the host)
+    int cull, tile_cap;            // cull = 1: every boresight is a unit vector (checked on the host);
+                                   // tile_cap: spectra per LDS tile of k_los (<= NXC_LOS_TILE)
     int n_lines, n_ladder;
     int64_t index_shift;           // subtracted from the index column: packet number inside its Output
     int64_t row_base;              // row number of the first sample of this launch (slabs)
@@ -1176,7 +1177,8 @@ struct LosK {
     LutDesc line[4];
 };
 
-constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile, all of them in LDS
+constexpr int NXC_LOS_TILE = 512;  // spectra per launch tile at most, all of them in LDS (LosK.tile_cap:
+                                   // fewer when large g-value tables leave less room)
 constexpr int NXC_LOS_SP = 7;      // doubles per spectrum there: position, boresight, cut-off
 #ifndef NXC_LOS_BLOCK_N             // (overridable: tools/ experiments)
 #define NXC_LOS_BLOCK_N 8
@@ -1603,8 +1605,8 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
 {
     static_assert(NXC_LOS_TILE <= 512, "a (group, spectrum) pair is 3 + 9 bits");
     stage_tables(blob, stage_bytes);
-    const int64_t s0 = (int64_t)blockIdx.y * NXC_LOS_TILE;
-    const int ns = (int)((S - s0) < NXC_LOS_TILE ? (S - s0) : NXC_LOS_TILE);
+    const int64_t s0 = (int64_t)blockIdx.y * K.tile_cap;
+    const int ns = (int)((S - s0) < K.tile_cap ? (S - s0) : K.tile_cap);
     double *tile = reinterpret_cast<double *>(nxc_lds + K.tile_off);
     // seven doubles per spectrum (the eighth, the ladder length, is only read where a pair is
     // decided): a stride of 14 banks, so the 32 different spectra a wave instruction of the
@@ -1618,7 +1620,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     unsigned long long my_pairs = 0, my_nonfinite = 0;
     unsigned long long wave_tests = 0;     // sphere tests of this wave (wave-uniform: scalar adds)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int qoff = (int)K.tile_off + NXC_LOS_TILE * NXC_LOS_SP * 8 + wid * NXC_LOS_WAVE_BYTES;
+    const int qoff = (int)K.tile_off + K.tile_cap * NXC_LOS_SP * 8 + wid * NXC_LOS_WAVE_BYTES;
     double *const sph = reinterpret_cast<double *>(nxc_lds + qoff + NXC_LOSQ_BYTES);
     double *const hsph = sph + 64 * 4;
     double *const gsph = hsph + 16 * 4;
@@ -1682,7 +1684,7 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
     // (the counter lives in the dynamic block, behind the last wave's lists: the kernels address
     // LDS from its start, so nothing static may sit in front)
     unsigned *const wg_next = reinterpret_cast<unsigned *>(
-        nxc_lds + K.tile_off + NXC_LOS_TILE * NXC_LOS_SP * 8 + (blockDim.x >> 6) * NXC_LOS_WAVE_BYTES);
+        nxc_lds + K.tile_off + K.tile_cap * NXC_LOS_SP * 8 + (blockDim.x >> 6) * NXC_LOS_WAVE_BYTES);
     if (threadIdx.x == 0) *wg_next = 0;
     __syncthreads();
     // (the next trip's spheres are on their way from memory while this one is worked through)

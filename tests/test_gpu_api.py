@@ -286,7 +286,10 @@ def test_los_block_formation_follows_any_index_column(ctx, layout):
     spectra = pd.DataFrame(dict(zip(POSITION + BORESIGHT, list(pos.T) + list(look.T))))
     cut, lengths, ladder = los_geometry(spectra, 25., dphi)
     sc = np.vstack([pos.T, look.T, cut, lengths.astype(float)])
-    gt = H.g_tables('Na', f.aplanet, f.R_km, (5891, 5897))
+    # ('packets': four emission lines -- 66 KB of g-value tables, which leave k_los a smaller tile
+    # of spectra in LDS: 200 spectra then take two tiles)
+    gt = H.g_tables('Na', f.aplanet, f.R_km,
+                    (3303, 5891, 5897, 5891) if layout == 'packets' else (5891, 5897))
     setup = (dphi, np.sin(dphi), np.sin(2*dphi), arccos_threshold(dphi), f.vrplanet, f.R_km*1e5,
              gt, ladder, sc)
     cols = [np.ascontiguousarray(c) for c in (pts[:, 0], pts[:, 1], pts[:, 2], vy, frac)]
