@@ -1092,7 +1092,9 @@ int los_run(nxc_handle *h, const nxc_los_desc *d, int64_t S, const double *sc, i
         constexpr int WPG = NXC_LOS_THREADS / 64;                  // waves per workgroup of k_los
         // the samples go through in slabs: the block scratch is sized for the worst case of one
         // slot per row (40 bytes; the bench cloud uses a fifth of a slot per row)
-        const int64_t slab = std::min<int64_t>(P, int64_t(1) << 24);
+        int64_t slab = std::min<int64_t>(P, int64_t(1) << 24);
+        if (const char *t = std::getenv("NXC_TEST_LOS_SLAB_ROWS"))       // tests: several slabs at small sizes
+            slab = std::max<int64_t>(256, std::min<int64_t>(slab, std::atoll(t)));
         // (every region may add 7 empty slots to complete its last group)
         const int64_t max_regions = (slab + NXC_LOS_FORM - 1) / NXC_LOS_FORM;
         const size_t max_slots = (size_t)(slab + 8 * max_regions);

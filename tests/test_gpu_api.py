@@ -255,7 +255,7 @@ def test_los_used_pairs_and_tiles(ctx):
 
 
 @pytest.mark.parametrize('layout', ['packets', 'no-index', 'scattered-index', 'tiny-packets'])
-def test_los_block_formation_follows_any_index_column(ctx, layout):
+def test_los_block_formation_follows_any_index_column(ctx, layout, monkeypatch):
     """k_los cuts the samples into blocks of at most 8 rows of ONE packet (the index column says
     where packets end) and culls on the blocks' and groups' bounding spheres.  Whatever the
     column looks like -- packets of 1..40 rows, packets of 1..3 rows, no column at all, ids in no
@@ -297,6 +297,15 @@ def test_los_block_formation_follows_any_index_column(ctx, layout):
     n_index = P if index is None else len(lens)
     res = ctx.los_accumulate(*setup, *cols, index=index, n_index=n_index, used_cap=400000)
     tests = ctx.counters()['samples']
+    # the samples go through in slabs of 2^24 rows; forced to three slabs here, the answers -- row
+    # numbers of the pair list and `included` slots too -- must not change
+    monkeypatch.setenv('NXC_TEST_LOS_SLAB_ROWS', str(P//3 + 1))
+    slabs = ctx.los_accumulate(*setup, *cols, index=index, n_index=n_index, used_cap=400000)
+    monkeypatch.delenv('NXC_TEST_LOS_SLAB_ROWS')
+    assert np.array_equal(slabs['npackets'], res['npackets']) and slabs['n_used'] == res['n_used']
+    assert np.array_equal(slabs['included'], res['included'])
+    assert set(zip(*slabs['used'].tolist())) == set(zip(*res['used'].tolist()))
+    np.testing.assert_allclose(slabs['radiance'], res['radiance'], rtol=1e-12, atol=0)
     smp = dict(x=cols[0], y=cols[1], z=cols[2], vy=vy, frac=frac,
                Index=np.arange(P) if index is None else index)
     scd = {c: spectra[c].values for c in spectra.columns}
