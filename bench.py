@@ -287,8 +287,56 @@ def stored_samples_leg(ctx, inputs, imgs, aplanet, vrplanet, quantity, n=1_000_0
         except (OSError, ValueError, KeyError):
             leg['tiles']['roofline']['traffic'] = None
         legs[label] = leg
-    store.free()
+    legs['_store'] = (store, out)
     return legs
+
+
+def synthetic_orbit(nspec, seed=0):
+    """Spacecraft positions on an eccentric ring (1.6 .. 2.9 R) with boresights in assorted
+    directions (a third roughly planetward): the MESSENGERuvvs stand-in of the kernel benches."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0, 2*np.pi, nspec, endpoint=False)
+    r = 1.6 + 1.3*np.cos(th)**2
+    pos = np.stack([0.3*r*np.cos(th), r*np.sin(th)*0.6 - 0.4, r*np.sin(th)*0.8], 1)
+    look = rng.normal(size=(nspec, 3))
+    look[::3] = -pos[::3] + 0.9*rng.normal(size=(len(pos[::3]), 3))
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    return pos, look
+
+
+def line_of_sight_leg(ctx, inputs, store, out, n_spectra=512):
+    """f-1 over STORED samples (data_simulation/compute_iteration.py:90-240): the resident float32
+    rows of the stored-samples leg against `n_spectra` synthetic lines of sight of 1 degree
+    half-angle; kernel time (k_los_blocks + k_los + k_los_pairs) by HIP events."""
+    from nexoclom_amd import LOSResult, SpacecraftData
+    from nexoclom_amd.LOSResult import arccos_threshold, los_geometry
+    pos, look = synthetic_orbit(n_spectra)
+    sc = SpacecraftData(pos[:, 0], pos[:, 1], pos[:, 2], look[:, 0], look[:, 1], look[:, 2])
+    with quiet():
+        los = LOSResult(sc, inputs, dphi=np.radians(1.0), context=ctx)
+    dist, lengths, ladder = los_geometry(sc.data, inputs.options.outeredge, los.dphi)
+    scarr = np.stack([sc.data.x, sc.data.y, sc.data.z, sc.data.xbore, sc.data.ybore,
+                      sc.data.zbore, dist, lengths.astype(float)])
+    args = (los.dphi, np.sin(los.dphi), np.sin(2*los.dphi), arccos_threshold(los.dphi),
+            float(out.vrplanet_Rs()), out.unit_km*1e5, los.g_tables(float(out.aplanet)), ladder,
+            scarr)
+    ms = []
+    for it in range(4):
+        res = ctx.los_accumulate(*args, rows=(store, 0, store.total, 0), n_index=out.npackets)
+        if it:
+            ms.append(ctx.last_kernel_ms())
+    k_ms = float(np.mean(ms))
+    P, S = int(store.total), n_spectra
+    ach = 40.0*P/(k_ms*1e-3)/1e9
+    return {'samples': P, 'spectra': S, 'kernel': 'k_los_blocks + k_los + k_los_pairs',
+            'kernel_ms': k_ms, 'pairs_decided_per_s': P*S/(k_ms*1e-3),
+            'samples_per_s': P/(k_ms*1e-3), 'pairs_inside_cones': int(res['npackets'].sum()),
+            'bounding_sphere_tests': int(ctx.counters()['samples']),
+            'roofline': {'bound': 'latency of wave-synchronous LDS stages', 'contract_bound': 'hbm',
+                         'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
+                         'frac': ach/HBM_PEAK_GBS,
+                         'note': '40 algorithmic bytes per stored sample, read once for all '
+                                 f'{S} spectra of the launch'}}
 
 
 def fail_line(args, world, reason):
@@ -625,6 +673,10 @@ def _run_rank(args, cp, make_context, emit, state, on_peer_failure):
             line['stored_samples_image'] = legs[f'{args.dims}x{args.dims}']
             # the reference's default image size (ModelImage.py:53)
             line['stored_samples_image_800'] = legs['800x800']
+            # the other half of data_simulation: spacecraft lines of sight over the same rows
+            store, out_rows = legs['_store']
+            line['line_of_sight'] = line_of_sight_leg(ctx, inputs, store, out_rows)
+            store.free()
             # the adaptive-step driver (a-4), for the record: at the reference's chunk of 1e6
             # packets (Input.py:218) and at 1e7, which is what Input.run launches at once
             line['variable_step'] = variable_leg(ctx, inputs_var, 1_000_000)
