@@ -1424,7 +1424,10 @@ NXC_DEV long long los_place_apply(const LosPlace &f, long long pos)
 // next region: one block in thirty more than strictly needed).  The region's slots -- a whole
 // number of groups -- go to the next free place of ONE stream of slots (a returning atomic per
 // region; the order of the regions in the stream does not matter), so that k_los reads dense trips.
-constexpr int NXC_LOS_BLOCKS_THREADS = 1024;     // 16 regions per workgroup, one atomic for all of them
+#ifndef NXC_LOS_BLOCKS_THREADS_N
+#define NXC_LOS_BLOCKS_THREADS_N 1024
+#endif
+constexpr int NXC_LOS_BLOCKS_THREADS = NXC_LOS_BLOCKS_THREADS_N;     // 16 regions per workgroup, one atomic for all of them
 template <typename T, typename I>
 __global__ void __launch_bounds__(NXC_LOS_BLOCKS_THREADS)
 k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__ y,
