@@ -24,6 +24,8 @@ Vectors
   g4_var.npz        variable driver around the reference rk5, 128 packets
   g5_hist.npz       Histogram2d edge cases at 512x512 (on-edge, right edge, outside)
   g6_rotation.npz   rotation_matrix / image_rotation for several sub-observer points
+  g9_var2000.npz    the adaptive driver around the reference's rk5 on 2000 packets of the bench
+                    workload at random ages: attempts in total, final states and stored steps
   g8_const20k.npz   the bench workload at BASELINE's image geometry, around the reference's rk5:
                     20 000 packets (X0 = tests.helpers.sample_x0(20000, 8008, 50000.), not
                     stored) x all 1667 steps: per-packet step counts, alive count and sum(frac)
@@ -175,6 +177,18 @@ def main():
     assert w_ref == w_o and np.array_equal(fin_ref, fin_o) and np.array_equal(hs_ref, hs_o)
     np.savez_compressed(os.path.join(OUT, 'g4_var.npz'), X0=X0, final=fin_ref, step_size=hs_ref,
                         work=np.int64(w_ref), params=np.array([1e-4, 25.0]))
+
+    # ---- G9: the adaptive driver on 2000 packets of the bench workload ---------------------------
+    f = H.mercury_forces('Na', 1.3)
+    X0 = H.sample_x0(2000, 909, 50000.)
+    X0[:, 0] = np.random.default_rng(99).random(2000)*50000.
+    out = ref_loader.duck_output(f, 0)
+    fin_ref, hs_ref, w_ref = O.variable_step_driver(
+        f, X0, 1e-4, 25.0, rk5_fn=lambda X, h: rk5m.rk5(out, X, h))
+    fin_o, hs_o, w_o = O.variable_step_driver(f, X0, 1e-4, 25.0)
+    assert w_ref == w_o and np.array_equal(fin_ref, fin_o) and np.array_equal(hs_ref, hs_o)
+    np.savez_compressed(os.path.join(OUT, 'g9_var2000.npz'), X0=X0, final=fin_ref,
+                        step_size=hs_ref, work=np.int64(w_ref), params=np.array([1e-4, 25.0]))
 
     # ---- G5 histogram edge cases --------------------------------------------------------------
     rng = np.random.default_rng(5)

@@ -200,3 +200,23 @@ def test_histogram_edge_cases_against_the_reference_vectors(ctx):
     assert cnt[511, :].sum() > 0          # samples == right-most edge land in the last bin
     ref, _, _ = np.histogram2d(px, pz, bins=[512, 512], range=[[-4, 4], [-4, 4]])
     assert np.array_equal(cnt.astype(float), ref)
+
+
+def test_variable_driver_against_g9_from_the_reference_rk5(ctx):
+    """g9_var2000.npz: 2000 packets of the bench workload at random ages through the reference's own
+    rk5.py in the adaptive driver (Output.py:221-366).  The kernels' error estimate uses the fused
+    tableau terms too, so its accept / reject decisions could in principle differ from the
+    reference's: the TOTAL number of attempts must be the reference's, every stored step size agree
+    to 1e-9 and every final state to 1e-8."""
+    g = load('g9_var2000.npz')
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    ctx.set_bounce(None); ctx.set_bodies(None)
+    res, edge = g['params']
+    ctx.upload_packets(g['X0'])
+    fin, hs = ctx.integrate_var(float(res), float(edge))
+    ctr = ctx.counters()
+    assert ctr['particle_steps'] == int(g['work']) > 5e5
+    assert ctr['unfinished'] == ctr['bad_step'] == ctr['nonfinite'] == ctr['neg_frac'] == 0
+    np.testing.assert_allclose(hs, g['step_size'], rtol=1e-9)
+    np.testing.assert_allclose(fin, g['final'], rtol=1e-8, atol=1e-12)

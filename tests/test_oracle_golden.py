@@ -112,6 +112,18 @@ def test_variable_driver_golden(coracle):
     np.testing.assert_allclose(fin_n, g['final'], rtol=1e-9, atol=1e-13)
 
 
+def test_variable_driver_golden_2000_packets(coracle):
+    """g9: the adaptive driver around the reference's rk5 on 2000 packets of the bench workload
+    -- the C checker (fused tableau terms in its error estimate) must make exactly as many attempts."""
+    g = load('g9_var2000.npz')
+    f = H.mercury_forces('Na', 1.3)
+    res, edge = g['params']
+    fin, hs, work, bad = coracle.integrate_var(f, g['X0'], res, edge)
+    assert bad == 0 and work == int(g['work']) > 5e5
+    np.testing.assert_allclose(hs, g['step_size'], rtol=1e-9)
+    np.testing.assert_allclose(fin, g['final'], rtol=1e-8, atol=1e-12)
+
+
 def test_histogram_edge_cases_golden(coracle):
     g = load('g5_hist.npz')
     f = H.mercury_forces('Na', 1.3)
