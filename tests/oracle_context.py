@@ -252,7 +252,6 @@ class OracleContext:
         if index is not None:
             smp['Index'] = np.asarray(index)
         scd = dict(zip(('x', 'y', 'z', 'xbore', 'ybore', 'zbore'), np.asarray(sc)[:6]))
-        outeredge = float(np.max(np.asarray(sc)[6]))
         radiance, npackets, included, used = O.los_iteration(
             smp, scd, dphi, self.los_outeredge, vrplanet, list(g_tables), unit_cm,
             n_index=n_index or None)
@@ -260,4 +259,4 @@ class OracleContext:
                          nonfinite=0, bad_step=0, neg_frac=0, unfinished=0)
         return dict(radiance=radiance, npackets=npackets, included=included, used=None, n_used=0)
 
-    los_outeredge = 25.0
+    los_outeredge = 25.0       # (the bench inputfile's; the restatement derives the cut-offs from it)
