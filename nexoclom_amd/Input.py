@@ -212,10 +212,9 @@ class Input:
                     outs = []
                     if together and sampler == 'numpy' and (group > 1 or pipeline):
                         # The Outputs are drawn on a few threads (NumPy releases the GIL in its
-                        # loops) a window ahead of the device, and a launch takes whatever is
-                        # drawn by the time the device is free -- at least one Output, at most what
-                        # HBM takes: the first launch starts after the first draws instead of
-                        # after a whole group's, and later launches find their Outputs waiting.
+                        # loops) a window ahead of the device, and a launch takes what is drawn by
+                        # the time the device is free: the first launch starts after the first
+                        # draws instead of after a whole group's, later ones find Outputs waiting.
                         if pool is None:
                             from collections import deque
                             from concurrent.futures import ThreadPoolExecutor
@@ -225,11 +224,20 @@ class Input:
                         while submitted < stop and len(pipeline) < window:
                             pipeline.append(draw_one(submitted))
                             submitted += 1
-                        outs = [pipeline.popleft().result()]
-                        # (a first launch of a handful keeps the device busy while the rest is drawn)
-                        ready_cap = limit if launched else max(1, min(limit, HOST_SAMPLER_THREADS))
+                        # A launch has a fixed cost of several milliseconds (two passes, row
+                        # offsets, a store): the first takes a handful of Outputs so that the
+                        # device starts early, the later ones wait for a third of what HBM takes
+                        # (or the rest of the pass) and then add whatever else is drawn by then.
+                        floor = max(1, min(limit, HOST_SAMPLER_THREADS)) if not launched else \
+                            max(1, min(limit//3, HOST_SAMPLER_THREADS*2))
                         launched = True
-                        while pipeline and pipeline[0].done() and len(outs) < ready_cap:
+                        outs = []
+                        while pipeline and len(outs) < floor:
+                            outs.append(pipeline.popleft().result())
+                            while submitted < stop and len(pipeline) < window:
+                                pipeline.append(draw_one(submitted))
+                                submitted += 1
+                        while pipeline and pipeline[0].done() and len(outs) < limit:
                             outs.append(pipeline.popleft().result())
                         number += len(outs)
                         drawn += size*len(outs)

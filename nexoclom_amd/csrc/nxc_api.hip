@@ -332,6 +332,7 @@ struct nxc_handle {
     PackedLut force_lut;
     std::vector<double> force_v, force_a;        // raw table (re-packed with fewer cells if LDS is short)
     int force_cells_per_node = 16;
+    int force_lut_cells = 0;                     // cells per node force_lut was packed with
     std::vector<unsigned char> image_part;       // lines, then xedges, zedges
     LdsHeader header{};                          // host copy of the blob's first bytes
     LutDesc line_local[NXC_MAX_LINES]{};         // relative to the table's own start ...
@@ -589,6 +590,7 @@ int upload_blob(nxc_handle *h)
                            "nxc_forces radiation table", h->force_cells_per_node);
         if (rc2) return rc2;
         h->force_lut = std::move(lut);
+        h->force_lut_cells = h->force_cells_per_node;
         fb = h->force_lut.bytes.size();
     }
     h->force_bytes = hb + fb;
@@ -1553,14 +1555,16 @@ int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
     PackedLut lut;
     const double zero_one[2] = {0.0, 1.0}, zeros[2] = {0.0, 0.0};
     int rc;
-    if (f->radpres) {
-        if (f->n_tab < 2 || !f->v_tab || !f->a_tab) return fail(NXC_ERR_ARG, "radiation table missing");
-        h->force_v.assign(f->v_tab, f->v_tab + f->n_tab);
-        h->force_a.assign(f->a_tab, f->a_tab + f->n_tab);
-    } else {
-        h->force_v.assign(zero_one, zero_one + 2);
-        h->force_a.assign(zeros, zeros + 2);
-    }
+    // (the launch groups of an Input.run set the same forces again and again: the packed table of
+    // the last call is kept when its nodes are the same)
+    const double *nv = f->radpres ? f->v_tab : zero_one, *na = f->radpres ? f->a_tab : zeros;
+    const size_t nn = f->radpres ? (size_t)(f->n_tab > 0 ? f->n_tab : 0) : 2;
+    if (f->radpres && (f->n_tab < 2 || !f->v_tab || !f->a_tab)) return fail(NXC_ERR_ARG, "radiation table missing");
+    const bool same_table = h->have_forces && h->force_v.size() == nn && !h->force_lut.bytes.empty() &&
+                            std::memcmp(h->force_v.data(), nv, nn * sizeof(double)) == 0 &&
+                            std::memcmp(h->force_a.data(), na, nn * sizeof(double)) == 0;
+    h->force_v.assign(nv, nv + nn);
+    h->force_a.assign(na, na + nn);
     // 8 cells per node: a cell then rarely holds two nodes (0.5 % of the Na table's cells against
     // 2 % at 4), so the two-row probe of lut_interp hits and the divergent walk mostly stays out
     // of the step loop; 16 measured slower again in the image kernel (LDS footprint).
@@ -1568,10 +1572,13 @@ int nxc_set_forces(nxc_handle *h, const nxc_forces *f)
 #ifdef NXC_EXPERIMENT_KNOBS
     if (const char *e = std::getenv("NXC_FORCE_CELLS")) h->force_cells_per_node = std::max(2, std::atoi(e));
 #endif
-    rc = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
-                  "nxc_forces radiation table", h->force_cells_per_node);
-    if (rc) return rc;
-    h->force_lut = std::move(lut);
+    if (!same_table || h->force_lut_cells != h->force_cells_per_node) {
+        rc = pack_lut(h->force_v.data(), h->force_a.data(), (int64_t)h->force_v.size(), lut,
+                      "nxc_forces radiation table", h->force_cells_per_node);
+        if (rc) { h->have_forces = false; return rc; }
+        h->force_lut = std::move(lut);
+        h->force_lut_cells = h->force_cells_per_node;
+    }
     h->F.GM = f->GM;
     h->F.vrplanet = f->vrplanet;
     h->F.photo = f->photo;
