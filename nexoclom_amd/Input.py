@@ -17,7 +17,7 @@ import time
 
 from . import input_classes as spec
 
-HOST_SAMPLER_THREADS = 8        # Outputs drawn side by side, ahead of the device (Input.run)
+HOST_SAMPLER_THREADS = 8        # Outputs drawn side by side, ahead of the device (16: no faster)
 
 # section name in the file -> (attribute on the Input, class that interprets it)
 SECTIONS = (('geometry', spec.Geometry), ('surfaceinteraction', spec.SurfaceInteraction),
