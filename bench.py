@@ -13,6 +13,10 @@ memory through the streamed upload ("incl. H2D of X0"),
 metric = particle*steps/s, whole job: sum over ranks of rk5 steps actually taken (active packets
 only, Output.py:385) / max-over-ranks wall time.
 
+Untimed extras of the N = 1 line (each with its own roofline object): the other image quantity,
+stored samples through the LDS tiles at 512 x 512 and at the reference's default 800 x 800, 512
+spacecraft lines of sight over the same stored samples, the adaptive driver at 1e6 and 1e7 packets.
+
     python bench.py --gpus 1 --steps 3 --warmup 1
     python bench.py --with-comm                # N = 1, but through every N > 1 branch (RCCL world of one)
     python bench.py --mode variable            # the adaptive-step driver (Output.py:221-366)
