@@ -75,6 +75,10 @@ int fail_hip(const char *expr, hipError_t e)
     } while (0)
 
 constexpr int BLOCK_PERSIST = NXC_BLOCK_PERSIST;
+#ifndef NXC_VAR_LEAN_PACKETS_PER_LANE_N      // (overridable: tools/gpu_exp_flags.sh)
+#define NXC_VAR_LEAN_PACKETS_PER_LANE_N 16
+#endif
+constexpr int NXC_VAR_LEAN_PACKETS_PER_LANE = NXC_VAR_LEAN_PACKETS_PER_LANE_N;
 static_assert(NXC_DEV_MAX_MOONS == NXC_MAX_MOONS, "device / ABI moon capacity");
 
 // ---- RCCL, resolved at first use ------------------------------------------------------------
@@ -2528,17 +2532,35 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     // flight_key); once per resident set
     if (h->order_key != 2 && (rc = order_on_device(h, -1.0, nullptr, 0, true))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
-    int grid = 1, block = BLOCK_PERSIST;
-    const size_t lds = persist_lds(h->force_bytes);
+    int grid = 1;
     const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
-    auto kernel = full ? k_var<true> : k_var<false>;
-    if ((rc = prep_kernel(kernel, lds))) return rc;
-    if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
-    if ((rc = begin_timed(h))) return rc;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
-                       (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
-                       h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge, (long long)max_steps,
-                       d_final, d_hs, h->d_ctr);
+    // few packets per lane: the launch lasts as long as its longest chain, and the code compiled
+    // for one wave per SIMD runs a chain 2.3 times faster (nxc_kernels.hpp: k_var)
+    constexpr int LEAN = 256;
+    bool lean = n < (int64_t)h->n_cu * BLOCK_PERSIST * NXC_VAR_LEAN_PACKETS_PER_LANE;
+    if (const char *t = std::getenv("NXC_TEST_VAR_VARIANT"))          // tests: both variants at any size
+        lean = t[0] == 'l';
+    int block = lean ? LEAN : BLOCK_PERSIST;
+    const size_t lds = ((h->force_bytes + 31) & ~size_t(31)) + (size_t)(block / 64) * NXC_WAVE_LDS_BYTES;
+    if (lean) {
+        auto kernel = full ? k_var<true, LEAN> : k_var<false, LEAN>;
+        if ((rc = prep_kernel(kernel, lds))) return rc;
+        if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
+        if ((rc = begin_timed(h))) return rc;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
+                           (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge,
+                           (long long)max_steps, d_final, d_hs, h->d_ctr);
+    } else {
+        auto kernel = full ? k_var<true> : k_var<false>;
+        if ((rc = prep_kernel(kernel, lds))) return rc;
+        if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
+        if ((rc = begin_timed(h))) return rc;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
+                           (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
+                           h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge,
+                           (long long)max_steps, d_final, d_hs, h->d_ctr);
+    }
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));

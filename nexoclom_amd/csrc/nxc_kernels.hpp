@@ -651,8 +651,14 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 //   errmax < 1e-7 -> errmax = 1 and h*10, which lands in the REJECT branch (errmax >= 1)  :294-300
 //   accept (errmax < 1): fate tests on r^2; the grown step is never stored  :302-327
 //   reject: stored step = max(0.95 h errmax^-0.25, 0.1 h)               :333-342
-template <bool FULL>      // FULL: gravity + radiation pressure + photo-loss known at compile time
-__global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
+// BLOCK: the launch bound the code is compiled for.  768 threads (three waves per SIMD, at most
+// 170 registers) give the highest throughput when every lane has dozens of packets to work
+// through; compiled for 256 (one wave per SIMD, up to 512 registers) the scheduler interleaves the
+// independent chains of an attempt far better -- 2.4 us per attempt for a wave that has its SIMD
+// to itself against 5.4 -- which is what counts when the launch is as long as its longest packet's
+// chain (1e6 packets: 29.8 ms against 33.7; 1e7: 172 against 151).
+template <bool FULL, int BLOCK = NXC_BLOCK_PERSIST>      // FULL: gravity + radiation pressure + photo-loss known at compile time
+__global__ void __launch_bounds__(BLOCK)
 k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
       const double *__restrict__ soa0, const unsigned *__restrict__ order, double resolution, double outeredge, long long max_steps,
       double *__restrict__ final_out, double *__restrict__ hstore_out,

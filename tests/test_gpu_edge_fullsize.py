@@ -158,14 +158,17 @@ def test_full_size_parity_against_the_c_oracle(ctx, coracle, n):
     np.testing.assert_allclose(image, c['image'], rtol=1e-10, atol=0)
 
 
-def test_variable_driver_parity_at_scale(ctx, coracle):
-    """2e5 packets through the adaptive driver (random start times, as Output.py:138-139):
+@pytest.mark.parametrize('variant', ['full', 'lean'])
+def test_variable_driver_parity_at_scale(ctx, coracle, variant, monkeypatch):
+    """4e5 packets through the adaptive driver (random start times, as Output.py:138-139):
     final states and stored step sizes bit-identical to the C oracle, same number of rk5
-    attempts."""
+    attempts -- for both compiled forms of k_var (768 and 256 lanes per workgroup; every lane of
+    either refills from the queue at this size)."""
     _needs_host_cores(coracle)
+    monkeypatch.setenv('NXC_TEST_VAR_VARIANT', variant)
     f = H.mercury_forces('Na', 1.3)
     H.set_ctx_forces(ctx, f)
-    n = 200_000
+    n = 400_000
     X0 = H.sample_x0(n, 555, 50000.)
     X0[:, 0] = np.random.default_rng(9).random(n)*50000.
     ctx.upload_packets(X0)

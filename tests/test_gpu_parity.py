@@ -222,7 +222,13 @@ def test_image_kernel_on_float32_samples_equals_the_restored_path(ctx, quantity)
     np.testing.assert_allclose(img32, img64, rtol=1e-12, atol=0)
 
 
-def test_variable_driver_bit_exact(ctx, coracle):
+@pytest.mark.parametrize('variant', ['by size', 'full', 'lean'])
+def test_variable_driver_bit_exact(ctx, coracle, variant, monkeypatch):
+    """k_var exists twice -- compiled for three waves per SIMD (many packets per lane) and for one
+    (few: the launch is then as long as its longest chain, and that code runs a chain faster).  The
+    library picks by size; NXC_TEST_VAR_VARIANT forces either: the same bits whichever runs."""
+    if variant != 'by size':
+        monkeypatch.setenv('NXC_TEST_VAR_VARIANT', variant)
     f = H.mercury_forces('Na', 1.3)
     H.set_ctx_forces(ctx, f)
     n, endtime = 5000, 20000.0
