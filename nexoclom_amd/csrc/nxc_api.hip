@@ -2530,12 +2530,15 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     double *d_final = h->d_scratch, *d_hs = d_final + 8 * n;
     // the adaptive driver's queue: slow packets with much time left first (nxc_kernels.hpp:
     // flight_key); once per resident set
+#ifdef NXC_VAR_TRACE      /* experiment: the packets as uploaded are the queue */
+    if (std::getenv("NXC_TEST_VAR_NO_ORDER")) { h->have_order = false; } else
+#endif
     if (h->order_key != 2 && (rc = order_on_device(h, -1.0, nullptr, 0, true))) return rc;
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     int grid = 1;
     const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
-    // few packets per lane: the launch lasts as long as its longest chain, and the code compiled
-    // for one wave per SIMD runs a chain 2.3 times faster (nxc_kernels.hpp: k_var)
+    // few packets per lane: the launch lasts as long as its longest chains, which run faster
+    // with two waves per SIMD than with three (nxc_kernels.hpp: k_var)
     constexpr int LEAN = 256;
     bool lean = n < (int64_t)h->n_cu * BLOCK_PERSIST * NXC_VAR_LEAN_PACKETS_PER_LANE;
     if (const char *t = std::getenv("NXC_TEST_VAR_VARIANT"))          // tests: both variants at any size
@@ -2570,6 +2573,13 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     return NXC_OK;
     });
 }
+
+#ifdef NXC_VAR_TRACE
+extern "C" int nxc_debug_var_trace(nxc_handle *h, unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_var_trace), sizeof(unsigned long long) * 8 * 4096) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int nxc_image_accumulate(nxc_handle *h, int64_t p, const double *x, const double *y,
                          const double *z, const double *vy, const double *frac)

@@ -651,12 +651,22 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 //   errmax < 1e-7 -> errmax = 1 and h*10, which lands in the REJECT branch (errmax >= 1)  :294-300
 //   accept (errmax < 1): fate tests on r^2; the grown step is never stored  :302-327
 //   reject: stored step = max(0.95 h errmax^-0.25, 0.1 h)               :333-342
-// BLOCK: the launch bound the code is compiled for.  768 threads (three waves per SIMD, at most
-// 170 registers) give the highest throughput when every lane has dozens of packets to work
-// through; compiled for 256 (one wave per SIMD, up to 512 registers) the scheduler interleaves the
-// independent chains of an attempt far better -- 2.4 us per attempt for a wave that has its SIMD
-// to itself against 5.4 -- which is what counts when the launch is as long as its longest packet's
-// chain (1e6 packets: 29.8 ms against 33.7; 1e7: 172 against 151).
+#ifdef NXC_VAR_TRACE          /* experiment (tools/gpu_exp_var_trace.py): per-wave times of k_var, 10 ns ticks */
+__device__ unsigned long long g_var_trace[8 * 4096];
+#endif
+// BLOCK: the workgroup size the kernel is launched with (the code is the same: 158 registers).  As
+// 768 threads a CU holds twelve waves, three per SIMD; as 256-thread workgroups the per-wave LDS
+// blocks and each workgroup's own copy of the tables admit two workgroups per CU, two waves per SIMD.
+// A SIMD issues for its OLDEST wave first (tools/gpu_exp_var_trace.py, 1e6 packets: 4.5 / 7.0 /
+// 13.6 us per trip for the three waves of a SIMD, 4.2 / 6.5 for two; 3.4 for a wave alone), and
+// the launch ends with the longest chains that happened to start late in a slow wave: with many
+// packets per lane three waves give the higher throughput (1e7: 151 ms against 172), with few the
+// two-wave launch ends sooner (1e6: 30.3 ms against 32.9).  The order of the queue decides the
+// rest -- longest first would end at 20-22 ms (tools/gpu_exp_var_order.py) -- but the reference's
+// controller only ever shrinks the stored step (Output.py:333-342), so a packet's attempts follow
+// from whether it survives its first returns to the surface: 10 % of the long chains misplaced
+// and the gain is gone (same tool), and neither launch state nor a pilot integration ranks them
+// better than that.
 template <bool FULL, int BLOCK = NXC_BLOCK_PERSIST>      // FULL: gravity + radiation pressure + photo-loss known at compile time
 __global__ void __launch_bounds__(BLOCK)
 k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
@@ -675,8 +685,17 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     long long id = -1, it = 0;
     unsigned my_trips = 0;
     double s[8], hs = 1000.0;
+#ifdef NXC_VAR_TRACE
+    const unsigned long long tr_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr_drain = 0, tr_low = 0;
+    unsigned tr_trips_drain = 0, tr_trips_low = 0;
+#endif
     for (;;) {
         const long long got = q.refill(!has, stage_off, s);
+#ifdef NXC_VAR_TRACE
+        if (q.drained && tr_drain == 0) { tr_drain = __builtin_amdgcn_s_memrealtime(); tr_trips_drain = my_trips; }
+        if (q.drained && tr_low == 0 && __popcll(__ballot(has)) <= 8) { tr_low = __builtin_amdgcn_s_memrealtime(); tr_trips_low = my_trips; }
+#endif
         if (got >= 0) {
             id = got; it = 0; hs = 1000.0; has = true;
         }
@@ -730,11 +749,24 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             if (done) {
 #pragma unroll
                 for (int c = 0; c < 8; c++) final_out[c * n + id] = s[c];
+#ifdef NXC_VAR_TRACE
+                if (hstore_out) hstore_out[id] = (double)it;   // experiment: the packet's attempts
+#else
                 if (hstore_out) hstore_out[id] = hs;
+#endif
                 has = false;
             }
         }
     }
+#ifdef NXC_VAR_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        // HW_REG_HW_ID (4): SIMD_ID = bits 5:4, WAVE_ID = bits 3:0
+        const unsigned hw = __builtin_amdgcn_s_getreg((5 << 11) | (0 << 6) | 4);
+        unsigned long long *tr = g_var_trace + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095);
+        tr[0] = tr_start; tr[1] = tr_drain; tr[2] = tr_low; tr[3] = __builtin_amdgcn_s_memrealtime();
+        tr[4] = my_trips; tr[5] = tr_trips_drain; tr[6] = tr_trips_low; tr[7] = hw;
+    }
+#endif
     flush_counter(&ctr->particle_steps, my_steps);
     if ((threadIdx.x & 63) == 0) atomicAdd(&ctr->wave_trips, (unsigned long long)my_trips);
     flush_counter(&ctr->nonfinite, my_nonfinite);

@@ -224,9 +224,10 @@ def test_image_kernel_on_float32_samples_equals_the_restored_path(ctx, quantity)
 
 @pytest.mark.parametrize('variant', ['by size', 'full', 'lean'])
 def test_variable_driver_bit_exact(ctx, coracle, variant, monkeypatch):
-    """k_var exists twice -- compiled for three waves per SIMD (many packets per lane) and for one
-    (few: the launch is then as long as its longest chain, and that code runs a chain faster).  The
-    library picks by size; NXC_TEST_VAR_VARIANT forces either: the same bits whichever runs."""
+    """k_var is launched as 768-thread workgroups (three waves per SIMD: many packets per lane) or
+    as 256-thread ones (two per SIMD: few -- the launch is then as long as its longest chains, which
+    run faster that way).  The library picks by size; NXC_TEST_VAR_VARIANT forces either: the same
+    bits whichever runs."""
     if variant != 'by size':
         monkeypatch.setenv('NXC_TEST_VAR_VARIANT', variant)
     f = H.mercury_forces('Na', 1.3)
