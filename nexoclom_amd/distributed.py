@@ -153,8 +153,10 @@ class ControlPlane:
                     magic, tok = hello[:5], hello[5:37].decode()
                     r, channel = struct.unpack('<II', hello[37:45])
                     table = (self._peers, self._watch_peers)[channel]
-                    if magic != _MAGIC or tok != token or not 0 < r < self.world or r in table:
+                    if magic != _MAGIC or tok != token or not 0 < r < self.world:
                         raise ConnectionError('bad hello')
+                    if r in table:                # the rank lost a half-made pair and dials again
+                        table.pop(r).close()
                 except (ConnectionError, OSError, struct.error, UnicodeDecodeError, MemoryError,
                         IndexError):
                     conn.close()
