@@ -1379,12 +1379,14 @@ NXC_DEV int wave_excl_max(int v, int &total)
 NXC_DEV bool los_sphere_hits(const double *__restrict__ sp, double cx, double cy, double cz, double R,
                              double tan_dphi)
 {
+    // (fused multiply-adds: nothing here is the reference's arithmetic -- the test only has to be
+    // conservative, and an fma rounds less than the mul + add it replaces; 19 instructions, not 26)
     const double rx = cx - sp[0], ry = cy - sp[1], rz = cz - sp[2];
-    const double qc = (rx * sp[3] + ry * sp[4]) + rz * sp[5];
-    const double perp2 = ((rx * rx + ry * ry) + rz * rz) - qc * qc;
-    const double lim = R + (qc + R) * tan_dphi;
+    const double qc = __builtin_fma(rz, sp[5], __builtin_fma(ry, sp[4], rx * sp[3]));
+    const double perp2 = __builtin_fma(-qc, qc, __builtin_fma(rz, rz, __builtin_fma(ry, ry, rx * rx)));
+    const double lim = __builtin_fma(qc + R, tan_dphi, R);
     return (R >= 0.0) && (qc + R > 0.0) && (qc - R < sp[6]) &&
-           !(perp2 > lim * lim * (1.0 + 1e-6) + 1e-9);
+           !(perp2 > __builtin_fma(lim * lim, 1.0 + 1e-6, 1e-9));
 }
 
 // T: double, or float for samples as Output.save() stores them (widened exactly, like restore());
@@ -1625,8 +1627,9 @@ k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__
 }
 
 constexpr int NXC_LOS_PAIRS = 512;       // (group, spectrum) survivors of 8 tests per lane
+constexpr int NXC_LOS_PAIRS2 = 256;      // (half, spectrum) survivors waiting for the block tests
 // per wave: candidate queue | 64 block | 16 half-group | 8 group spheres | pairs | (half, spectrum) pairs
-constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + 64 * 32 + 16 * 32 + 8 * 32 + NXC_LOS_PAIRS * 2 + 64 * 2;
+constexpr int NXC_LOS_WAVE_BYTES = NXC_LOSQ_BYTES + 64 * 32 + 16 * 32 + 8 * 32 + NXC_LOS_PAIRS * 2 + NXC_LOS_PAIRS2 * 2;
 #ifndef NXC_LOS_THREADS
 #define NXC_LOS_THREADS 1024
 #endif
@@ -1741,7 +1744,37 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
             x_ = u.x; y_ = u.y; z_ = v.x; r_ = v.y;
         }
     };
-    long long base, nbase;
+    long long base = 0, nbase;
+    int n2 = 0;                                       // (half, spectrum) pairs waiting in pairs2
+    auto block_tests = [&]() {
+        if (n2 == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int b0 = 0; b0 < n2; b0 += 16) {
+            const int bt = b0 + (lane >> 2);
+            bool bhit = false;
+            int j = 0, slot = 0;
+            if (bt < n2) {
+                const unsigned e = pairs2[bt];
+                slot = (int)(e >> 9) * 4 + (lane & 3);
+                j = (int)(e & 511u);
+                const double *q = sph + 4 * slot;
+                bhit = los_sphere_hits(tile + j * NXC_LOS_SP, q[0], q[1], q[2], q[3], K.tan_dphi);
+            }
+            wave_tests += 4 * (n2 - b0 < 16 ? n2 - b0 : 16);
+            // (one block test in 80 passes: its descriptor comes from memory then)
+            const long long bd = bhit ? (long long)bdesc[base + slot] : 0ll;
+#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 2
+            my_pairs += bhit && bd != 0;
+#else
+            queue.push(bhit, bd, j, qoff);
+            if (queue.waiting() >= 64) drain();
+#endif
+        }
+        __builtin_amdgcn_wave_barrier();              // pairs2 is rewritten from its start
+        n2 = 0;
+    };
     double cx, cy, cz, R, ncx, ncy, ncz, nR;
     take(nbase, ncx, ncy, ncz, nR);
     for (;;) {
@@ -1841,35 +1874,15 @@ k_los(LosK K, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64
                 }
                 wave_tests += 2 * (npair - at0 < 32 ? npair - at0 : 32);
                 const unsigned long long mask = __ballot(hit);
-                if (hit) pairs2[__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e2;
-                const int n2 = __popcll(mask);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int b0 = 0; b0 < n2; b0 += 16) {
-                    const int bt = b0 + (lane >> 2);
-                    bool bhit = false;
-                    int j = 0, slot = 0;
-                    if (bt < n2) {
-                        const unsigned e = pairs2[bt];
-                        slot = (int)(e >> 9) * 4 + (lane & 3);
-                        j = (int)(e & 511u);
-                        const double *q = sph + 4 * slot;
-                        bhit = los_sphere_hits(tile + j * NXC_LOS_SP, q[0], q[1], q[2], q[3], K.tan_dphi);
-                    }
-                    wave_tests += 4 * (n2 - b0 < 16 ? n2 - b0 : 16);
-                    // (one block test in 80 passes: its descriptor comes from memory then)
-                    const long long bd = bhit ? (long long)bdesc[base + slot] : 0ll;
-#if defined(NXC_LOS_EXPERIMENT) && NXC_LOS_EXPERIMENT >= 2
-                    my_pairs += bhit && bd != 0;
-#else
-                    queue.push(bhit, bd, j, qoff);
-                    if (queue.waiting() >= 64) drain();
-#endif
-                }
-                __builtin_amdgcn_wave_barrier();
+                if (hit) pairs2[n2 + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)e2;
+                n2 += __popcll(mask);
+                // the block tests wait until the list holds enough for full instructions (16 pairs
+                // each): taken after every 32 pairs they ran a third full
+                if (n2 > NXC_LOS_PAIRS2 - 64) block_tests();
             }
+            __builtin_amdgcn_wave_barrier();          // `pairs` is rewritten by the next 64 spectra
         }
+        block_tests();                                // before the spheres change
     }
     while (queue.waiting() > 0) drain();
     if (cur_chunk >= 0 && cur_chunk < pair_chunks && lane == 0) pair_fill[cur_chunk] = (unsigned)cur_fill;
