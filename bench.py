@@ -715,6 +715,8 @@ def main():
         sys.exit(1)
     if hip_api.device_count() < 1:
         cp.announce_failure('no HIP device')
+        if rank == 0:
+            print(json.dumps(fail_line(args, world, 'no HIP device (there is no CPU fallback)')), flush=True)
         raise SystemExit('bench.py needs a HIP device; there is no CPU fallback')
     rc = run_rank(args, cp, lambda: hip_api.Context(pick_device(cp)), hard_exit_after=45.0)
     sys.stdout.flush()
