@@ -120,6 +120,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise HipError(f'{LIB_PATH} not found: build it with `python -m nexoclom_amd.build` '
                        '(there is no CPU fallback for the hot path)')
+    # several processes on one node (RCCL, shared device memory): this pool's host driver only
+    # supports dmabuf IPC; without the setting ncclCommInitRank fails in hipIpcGetMemHandle.  Read
+    # by the runtime when it initialises, i.e. at the first HIP call -- none has been made yet.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     lib = C.CDLL(LIB_PATH)
     lib.nxc_last_error_string.restype = C.c_char_p
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
