@@ -359,7 +359,11 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
                                  double step, int64_t n_iter, double outeredge, uint32_t flags);
 
 /* ---- a-4: variable-step driver over the resident packets ---------------------------------------
- * final_out host [8][n]; hstore_out (nullable) host [n] = stored step_size column at exit. */
+ * final_out host [8][n]; hstore_out (nullable) host [n] = stored step_size column at exit.
+ * One persistent launch; the queue is ordered by remaining time over launch speed.  Launched as
+ * 768-thread workgroups (three waves per SIMD) from 16 packets per lane up, as 256-thread ones
+ * (two per SIMD) below: same code, same bits (the environment variable NXC_TEST_VAR_VARIANT =
+ * "full" / "lean" forces either, for tests). */
 int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,
                       double *final_out, double *hstore_out);
 
