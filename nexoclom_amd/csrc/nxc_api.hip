@@ -306,9 +306,12 @@ struct nxc_rows {
     size_t cols_cap = 0, index_cap = 0;      // bytes of the two blocks (they may come from the pool)
 };
 
-// Device blocks of freed row stores, kept for the next store: hipFree / hipMalloc of tens of GB
-// cost about a second per 60 GB (a catalogue that is dropped and re-run pays it twice).  The pool
-// counts as free memory (nxc_mem_info) and is emptied before anything is refused for lack of it.
+// Device blocks of freed row stores, kept for the next store.  hipMalloc / hipFree themselves return
+// in under a millisecond on this driver (now and then 30-150 ms beside a running kernel); what a
+// fresh block costs is its first touch -- a 51 GB catalogue written into new memory takes about
+// 0.1 s longer than into pooled blocks (NXC_POOL_TRACE=1 prints every take and give;
+// tools/gpu_exp_run_breakdown.py).  The pool counts as free memory (nxc_mem_info) and is emptied
+// before anything is refused for lack of it.
 struct BlockPool {
     struct Block { void *p; size_t bytes; };
     std::vector<Block> blocks;
@@ -505,6 +508,10 @@ int ensure(void **ptr, size_t *cap, size_t bytes)
     return NXC_OK;
 }
 
+// NXC_POOL_TRACE=1: every take / give that reaches the driver, with its duration, on stderr
+const bool g_pool_trace = std::getenv("NXC_POOL_TRACE") != nullptr;
+size_t pool_bytes(nxc_handle *h);
+
 void pool_flush(nxc_handle *h)
 {
     std::lock_guard<std::mutex> g(h->pool.lock);
@@ -531,10 +538,18 @@ hipError_t pool_take(nxc_handle *h, size_t bytes, void **out, size_t *cap)
             *cap = h->pool.blocks[(size_t)best].bytes;
             h->pool.bytes -= *cap;
             h->pool.blocks.erase(h->pool.blocks.begin() + best);
+            if (g_pool_trace) std::fprintf(stderr, "[nxc pool] hit  %8.1f MB in a block of %8.1f MB\n", bytes / 1e6, *cap / 1e6);
             return hipSuccess;
         }
     }
+    timespec t0{}, t1{};
+    if (g_pool_trace) clock_gettime(CLOCK_MONOTONIC, &t0);
     hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+    if (g_pool_trace) {
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        std::fprintf(stderr, "[nxc pool] miss %8.1f MB: hipMalloc %.1f ms (pool holds %.1f MB in %zu blocks)\n", bytes / 1e6,
+                     (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, pool_bytes(h) / 1e6, h->pool.blocks.size());
+    }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         pool_flush(h);
@@ -553,7 +568,14 @@ void pool_give(nxc_handle *h, void *p, size_t bytes)
     // small blocks are cheap to allocate; the pool never holds more than a third of the device
     if (!known || bytes < (size_t(64) << 20) || h->pool.bytes + bytes > total_b / 3 ||
         h->pool.blocks.size() >= 64) {
+        timespec t0{}, t1{};
+        if (g_pool_trace) clock_gettime(CLOCK_MONOTONIC, &t0);
         (void)hipFree(p);
+        if (g_pool_trace && bytes >= (size_t(64) << 20)) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            std::fprintf(stderr, "[nxc pool] full: hipFree of %8.1f MB %.1f ms\n", bytes / 1e6,
+                         (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+        }
         return;
     }
     h->pool.blocks.push_back({p, bytes});
