@@ -825,7 +825,10 @@ k_image(const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t p,
 // up to 512^2 pixels (262 144), 64 of 128 up to 524 288, 128 of 64 up to 1024^2 (the reference's
 // default 800 x 800, ModelImage.py:53, takes 128 tiles of 7 image rows).  A chunk of 64 still
 // leaves as 512 + 128 contiguous bytes.  Larger images stay with k_image.
-constexpr int NXC_TILE_STAGE = 8192;        // staged entries per workgroup of pass 1 (all tiles)
+#ifndef NXC_TILE_STAGE_N          // (overridable: tools/gpu_exp_tile_occupancy.sh)
+#define NXC_TILE_STAGE_N 8192
+#endif
+constexpr int NXC_TILE_STAGE = NXC_TILE_STAGE_N;   // staged entries per workgroup of pass 1 (all tiles)
 constexpr int NXC_TILE_MAX = 128;           // tiles per image at most
 constexpr int NXC_TILE_PIXELS = 8192;       // pixels per tile at most (96 KB of LDS)
 #ifndef NXC_TILE_UNROLL_N
