@@ -305,7 +305,7 @@ def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
     with pytest.raises(hip_api.HipError, match='did not complete within 0.4 s') as err:
         ctx.synchronize()
     waited = time.perf_counter() - t0
-    assert err.value.code == hip_api.NXC_ERR_RCCL and 0.35 < waited < 3.0
+    assert err.value.code == hip_api.NXC_ERR_RCCL and 0.35 < waited < 8.0     # (2 s + a loaded box)
     with pytest.raises(hip_api.HipError, match='nxc_comm_init'):      # no communicator any more
         ctx.image_allreduce()
     ctx.synchronize()                                                  # the stall ends by itself
@@ -319,7 +319,7 @@ def test_a_collective_that_never_completes_ends_at_its_deadline(ctx):
     t0 = time.perf_counter()
     with pytest.raises(hip_api.HipError, match='peer rank reported a failure') as err:
         ctx.synchronize()
-    assert err.value.code == hip_api.NXC_ERR_RCCL and time.perf_counter() - t0 < 3.0
+    assert err.value.code == hip_api.NXC_ERR_RCCL and time.perf_counter() - t0 < 8.0
     ctx.synchronize()
     # the handle works on: a fresh communicator, a collective, a pass
     ctx.comm_init(ctx.comm_unique_id(), 0, 1)
