@@ -268,7 +268,7 @@ def _worker_two_stage(rank, world, port, tmpdir, kind):
     cp.close()
 
 
-@pytest.mark.parametrize('kind,world', [('tcp', 2), ('gloo', 2), ('tcp', 3)])
+@pytest.mark.parametrize('kind,world', [('tcp', 2), ('gloo', 2), ('tcp', 3), ('tcp', 8)])   # 8: three ranks without an Output
 def test_two_stage_flow_and_los_shared_by_ranks_equal_one_rank(tmp_path, kind, world):
     port = 29300 + os.getpid() % 300 + 7*world + (11 if kind == 'gloo' else 0)
     ctx = mp.get_context('spawn')
