@@ -87,3 +87,71 @@ def test_random_configuration_parity(ctx, coracle, seed):
     vf, vh = ctx.integrate_var(res, outeredge)
     cf, chs, work, bad = coracle.integrate_var(f, Xv, res, outeredge)
     assert bad == 0 and np.array_equal(vf, cf) and np.array_equal(vh, chs)
+
+
+def _random_los_case(seed):
+    import pandas as pd
+    from nexoclom_amd.LOSResult import POSITION, BORESIGHT, arccos_threshold, los_geometry
+    rng = np.random.default_rng(5000 + seed)
+    f = H.mercury_forces('Na', float(rng.uniform(0, 2*np.pi)))
+    nspec = int(rng.choice([1, 7, 64, 65, 200, 513, 700]))
+    dphi = np.radians(float(rng.choice([0.3, 1.0, 2.0, 5.0, 8.0])))
+    outeredge = float(rng.choice([8.0, 25.0]))
+    top = int(rng.choice([1, 3, 12, 40, 200]))
+    npk = int(rng.integers(200, 3000))
+    lens = rng.integers(1, top + 1, npk)
+    P = int(lens.sum())
+    ids = np.repeat(np.arange(npk), lens)
+    start = rng.normal(0, float(rng.choice([0.7, 1.5, 4.0])), (npk, 3))
+    vel = rng.normal(0, float(rng.choice([1e-3, 0.04, 0.3])), (npk, 3))
+    k = np.arange(P) - np.repeat(np.cumsum(lens) - lens, lens)
+    pts = start[ids] + vel[ids]*k[:, None]
+    vy = rng.normal(0, 2e-3, P)
+    frac = rng.uniform(0.05, 1, P)
+    dist = rng.uniform(1.1, float(rng.choice([3.0, 20.0])), nspec)
+    pos = rng.normal(size=(nspec, 3)); pos *= (dist/np.linalg.norm(pos, axis=1))[:, None]
+    look = rng.normal(size=(nspec, 3))
+    toward = rng.random(nspec) < 0.5                       # half of them roughly at the cloud
+    look[toward] = -pos[toward] + 0.5*rng.normal(size=(int(toward.sum()), 3))
+    look /= np.linalg.norm(look, axis=1)[:, None]
+    spectra = pd.DataFrame(dict(zip(POSITION + BORESIGHT, list(pos.T) + list(look.T))))
+    cut, lengths, ladder = los_geometry(spectra, outeredge, dphi)
+    sc = np.vstack([pos.T, look.T, cut, lengths.astype(float)])
+    gt = H.g_tables('Na', f.aplanet, f.R_km, (5891, 5897))
+    setup = (dphi, np.sin(dphi), np.sin(2*dphi), arccos_threshold(dphi), f.vrplanet, f.R_km*1e5,
+             gt, ladder, sc)
+    cols = [np.ascontiguousarray(c) for c in (pts[:, 0], pts[:, 1], pts[:, 2], vy, frac)]
+    use_index = bool(rng.random() < 0.7)
+    slabs = int(rng.integers(2, 5)) if rng.random() < 0.5 else 0
+    smp = dict(x=cols[0], y=cols[1], z=cols[2], vy=vy, frac=frac,
+               Index=ids.astype(np.int64) if use_index else np.arange(P))
+    scd = {c: spectra[c].values for c in spectra.columns}
+    oracle_args = (smp, scd, dphi, outeredge, f.vrplanet, gt, f.R_km*1e5)
+    return dict(setup=setup, cols=cols, index=ids.astype(np.int64) if use_index else None,
+                n_index=npk if use_index else P, P=P, slabs=slabs, oracle_args=oracle_args)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('NXC_FUZZ_LOS_SEEDS', '8'))))   # soak: more
+def test_random_line_of_sight_geometry_parity(ctx, seed):
+    """f-1 over random geometry: cone half-angle 0.3..8 degrees, 1..700 lines of sight from 1.1 to
+    20 R looking anywhere, packets as straight flights of random length, speed and spread (so the
+    bounding spheres of blocks, half groups and groups come in every size against the cones), with
+    or without an index column, in one or several slabs.  Against the KD-tree restatement of
+    compute_iteration.py: packet counts, `included` and the (spectrum, sample) pair list exactly,
+    radiance to 1e-10 -- the three levels of sphere culling (fused multiply-adds with slack) may
+    never lose a pair the exact test would accept."""
+    case = _random_los_case(seed)
+    if case['slabs']:
+        os.environ['NXC_TEST_LOS_SLAB_ROWS'] = str(case['P']//case['slabs'] + 1)
+    try:
+        res = ctx.los_accumulate(*case['setup'], *case['cols'], index=case['index'],
+                                 n_index=case['n_index'], used_cap=2_000_000)
+    finally:
+        os.environ.pop('NXC_TEST_LOS_SLAB_ROWS', None)
+    r, n, inc, used = O.los_iteration(*case['oracle_args'], n_index=case['n_index'])
+    assert np.array_equal(res['npackets'], n), (seed, int(np.abs(res['npackets'] - n).sum()))
+    assert np.array_equal(res['included'], inc)
+    np.testing.assert_allclose(res['radiance'], r, rtol=1e-10, atol=0)
+    pairs = set(zip(res['used'][0].tolist(), res['used'][1].tolist()))
+    assert res['n_used'] == len(pairs) == sum(len(u) for u in used)
+    assert pairs == {(i, int(row)) for i, rows in enumerate(used) for row in rows}
