@@ -1560,7 +1560,7 @@ int nxc_synchronize(nxc_handle *h)
         HIPCHK(hipMemcpy(&c, h->d_ctr, sizeof c, hipMemcpyDeviceToHost));
         if (c.unfinished != 0) {
             h->n_packets = 0;                  // the queue holds a partly ordered set: upload again
-            char buf[256];
+            char buf[400];
             std::snprintf(buf, sizeof buf,
                           "the pipelined pass gave up waiting for its queue (%llu packets not "
                           "integrated): the ordering kernels did not run beside the persistent "

@@ -1472,6 +1472,7 @@ NXC_DEV long long los_place_apply(const LosPlace &f, long long pos)
 #endif
 constexpr int NXC_LOS_BLOCKS_THREADS = NXC_LOS_BLOCKS_THREADS_N;     // 16 regions per workgroup, one atomic for all of them
 template <typename T, typename I>
+// (capped at 64 registers so that two workgroups share a CU: measured no faster, 113 against 116 us)
 __global__ void __launch_bounds__(NXC_LOS_BLOCKS_THREADS)
 k_los_blocks(int64_t P, int cull, const T *__restrict__ x, const T *__restrict__ y,
              const T *__restrict__ z, const I *__restrict__ index,
