@@ -360,10 +360,11 @@ int nxc_integrate_const_streamed(nxc_handle *h, int64_t n, const double *soa0, i
 
 /* ---- a-4: variable-step driver over the resident packets ---------------------------------------
  * final_out host [8][n]; hstore_out (nullable) host [n] = stored step_size column at exit.
- * One persistent launch; the queue is ordered by remaining time over launch speed.  Launched as
- * 768-thread workgroups (three waves per SIMD) from 16 packets per lane up, as 256-thread ones
- * (two per SIMD) below: same code, same bits (the environment variable NXC_TEST_VAR_VARIANT =
- * "full" / "lean" forces either, for tests). */
+ * One persistent launch; the queue is ordered by remaining time over launch speed.  Under 24
+ * packets per lane (4.7e6 packets) the waves of a SIMD take turns at issue priority and, once the
+ * queue is drained, sparse waves hand their live packets to one wave per SIMD; above it the plain
+ * form: same arithmetic, same bits (the environment variable NXC_TEST_VAR_VARIANT = "fair" /
+ * "plain" forces either, for tests). */
 int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_t max_steps,
                       double *final_out, double *hstore_out);
 

@@ -75,10 +75,10 @@ int fail_hip(const char *expr, hipError_t e)
     } while (0)
 
 constexpr int BLOCK_PERSIST = NXC_BLOCK_PERSIST;
-#ifndef NXC_VAR_LEAN_PACKETS_PER_LANE_N      // (overridable: tools/gpu_exp_flags.sh)
-#define NXC_VAR_LEAN_PACKETS_PER_LANE_N 16
+#ifndef NXC_VAR_FAIR_PACKETS_PER_LANE_N       // (tools/gpu_exp_var_forms.sh)
+#define NXC_VAR_FAIR_PACKETS_PER_LANE_N 24
 #endif
-constexpr int NXC_VAR_LEAN_PACKETS_PER_LANE = NXC_VAR_LEAN_PACKETS_PER_LANE_N;
+constexpr double NXC_VAR_FAIR_PACKETS_PER_LANE = NXC_VAR_FAIR_PACKETS_PER_LANE_N;
 static_assert(NXC_DEV_MAX_MOONS == NXC_MAX_MOONS, "device / ABI moon capacity");
 
 // ---- RCCL, resolved at first use ------------------------------------------------------------
@@ -2559,33 +2559,29 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
     HIPCHK(hipMemsetAsync(h->d_ctr, 0, sizeof(DevCounters), h->stream));
     int grid = 1;
     const bool full = h->F.grav && h->F.rad && h->F.loss == LOSS_PHOTO;
-    // few packets per lane: the launch lasts as long as its longest chains, which run faster
-    // with two waves per SIMD than with three (nxc_kernels.hpp: k_var)
-    constexpr int LEAN = 256;
-    bool lean = n < (int64_t)h->n_cu * BLOCK_PERSIST * NXC_VAR_LEAN_PACKETS_PER_LANE;
-    if (const char *t = std::getenv("NXC_TEST_VAR_VARIANT"))          // tests: both variants at any size
-        lean = t[0] == 'l';
-    int block = lean ? LEAN : BLOCK_PERSIST;
+    // Two launch forms of the same arithmetic (nxc_kernels.hpp: k_var), by packets per lane: under
+    // 24 (4.7e6 packets: the launch is mostly tail) with clock-rotated wave priorities and a merged
+    // tail, above it plain (highest throughput).
+    const double per_lane = (double)n / ((double)h->n_cu * BLOCK_PERSIST);
+    bool fair = per_lane < NXC_VAR_FAIR_PACKETS_PER_LANE;
+    if (const char *t = std::getenv("NXC_TEST_VAR_VARIANT"))          // tests: both forms at any size
+        fair = t[0] == 'f';                                           // "fair" / "plain"
+    int block = BLOCK_PERSIST;
     const size_t lds = ((h->force_bytes + 31) & ~size_t(31)) + (size_t)(block / 64) * NXC_WAVE_LDS_BYTES;
-    if (lean) {
-        auto kernel = full ? k_var<true, LEAN> : k_var<false, LEAN>;
-        if ((rc = prep_kernel(kernel, lds))) return rc;
-        if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
-        if ((rc = begin_timed(h))) return rc;
+    auto launch = [&](auto kernel) -> int {
+        int rc2;
+        if ((rc2 = prep_kernel(kernel, lds))) return rc2;
+        if ((rc2 = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc2;
+        if ((rc2 = begin_timed(h))) return rc2;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
                            (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
                            h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge,
                            (long long)max_steps, d_final, d_hs, h->d_ctr);
-    } else {
-        auto kernel = full ? k_var<true> : k_var<false>;
-        if ((rc = prep_kernel(kernel, lds))) return rc;
-        if ((rc = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc;
-        if ((rc = begin_timed(h))) return rc;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
-                           (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
-                           h->have_order ? h->d_order : (const unsigned *)nullptr, resolution, outeredge,
-                           (long long)max_steps, d_final, d_hs, h->d_ctr);
-    }
+        return NXC_OK;
+    };
+    if (fair) rc = full ? launch(k_var<true, true>) : launch(k_var<false, true>);
+    else rc = full ? launch(k_var<true, false>) : launch(k_var<false, false>);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     if ((rc = end_timed(h))) return rc;
     HIPCHK(hipMemcpyAsync(final_out, d_final, 8 * col, hipMemcpyDeviceToHost, h->stream));

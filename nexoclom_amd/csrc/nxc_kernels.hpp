@@ -654,33 +654,99 @@ k_const_fused(ForceK F, const unsigned char *__restrict__ blob,
 #ifdef NXC_VAR_TRACE          /* experiment (tools/gpu_exp_var_trace.py): per-wave times of k_var, 10 ns ticks */
 __device__ unsigned long long g_var_trace[8 * 4096];
 #endif
-// BLOCK: the workgroup size the kernel is launched with (the code is the same: 158 registers).  As
-// 768 threads a CU holds twelve waves, three per SIMD; as 256-thread workgroups the per-wave LDS
-// blocks and each workgroup's own copy of the tables admit two workgroups per CU, two waves per SIMD.
-// A SIMD issues for its OLDEST wave first (tools/gpu_exp_var_trace.py, 1e6 packets: 4.5 / 7.0 /
-// 13.6 us per trip for the three waves of a SIMD, 4.2 / 6.5 for two; 3.4 for a wave alone), and
-// the launch ends with the longest chains that happened to start late in a slow wave: with many
-// packets per lane three waves give the higher throughput (1e7: 151 ms against 172), with few the
-// two-wave launch ends sooner (1e6: 30.3 ms against 32.9).  The order of the queue decides the
-// rest -- longest first would end at 20-22 ms (tools/gpu_exp_var_order.py) -- but the reference's
-// controller only ever shrinks the stored step (Output.py:333-342), so a packet's attempts follow
-// from whether it survives its first returns to the surface: 10 % of the long chains misplaced
-// and the gain is gone (same tool), and neither launch state nor a pilot integration ranks them
-// better than that.
-template <bool FULL, int BLOCK = NXC_BLOCK_PERSIST>      // FULL: gravity + radiation pressure + photo-loss known at compile time
-__global__ void __launch_bounds__(BLOCK)
+// FAIR SHARES AND A MERGED TAIL (the 768-thread form; NXC_VAR_FAIR).  A SIMD issues for its oldest
+// wave first, so of the three waves of a SIMD one makes a trip every 4.5 us and another every
+// 13.6 (tools/gpu_exp_var_trace.py) -- and the launch ends with the long chains that sat in a slow
+// wave while the queue lasted.  Two measures: (1) s_setprio, rotated by the clock (every wave of a
+// SIMD leads a third of the time, slices of 41 us): all waves at 6.6-7.3 us per trip; (2) once the
+// queue is drained the waves only lose lanes, and three sparse waves share the SIMD's issue slots:
+// the first wave of each SIMD to register is its KEEPER, every other wave a DONOR that -- queue
+// drained, at most NXC_VAR_MERGE_MAX lanes live -- reserves that many lanes of a keeper (`room`, one
+// LDS atomic, undone if it overdraws), writes its packets {state, stored step, attempts, id}, bit
+// for bit, into its own LDS block, publishes {count, keeper} and ends; the keeper adopts them on
+// its next trip.  A keeper leaves when every wave of the workgroup has published (a wave that
+// ends on its own publishes 0) and nothing addressed to it is left.  Tallies stay with the lane
+// that made the attempt: totals do not move.
+#ifndef NXC_VAR_FAIR
+#define NXC_VAR_FAIR 1
+#endif
+#ifndef NXC_VAR_MERGE_MAX_N
+#define NXC_VAR_MERGE_MAX_N 48
+#endif
+#ifndef NXC_VAR_PRIO_SHIFT
+#define NXC_VAR_PRIO_SHIFT 12          /* slices of 2^12 x 10 ns */
+#endif
+constexpr int NXC_VAR_MERGE_MAX = NXC_VAR_MERGE_MAX_N;      // x 11 doubles, from the start of the wave's block
+constexpr int NXC_VAR_HDR_OFF = NXC_WAVE_LDS_BYTES - 64;    // the block's last 64 bytes (image queue: unused here)
+constexpr unsigned NXC_VAR_PENDING = 0xffffffffu;
+static_assert(NXC_VAR_MERGE_MAX * 11 * 8 <= NXC_VAR_HDR_OFF && NXC_VAR_HDR_OFF >= NXC_WAVE_STAGE_BYTES,
+              "a donor's packets and the header share the wave's block with the staging area");
+struct VarMerge {
+    int wave0;             // LDS byte offset of wave 0's block
+    NXC_DEV NXC_LDS_AS double *seg(int w) const
+    {
+        return (NXC_LDS_AS double *)(unsigned)(wave0 + w * NXC_WAVE_LDS_BYTES);
+    }
+    // wave w: [0] published count, [1] keeper addressed, [2] adopted; wave 0 also: [4..7] room, [8..11] registrations
+    NXC_DEV NXC_LDS_AS unsigned *hdr(int w) const
+    {
+        return (NXC_LDS_AS unsigned *)(unsigned)(wave0 + w * NXC_WAVE_LDS_BYTES + NXC_VAR_HDR_OFF);
+    }
+    NXC_DEV NXC_LDS_AS int *room(int k) const { return (NXC_LDS_AS int *)(hdr(0) + 4 + k); }
+    NXC_DEV static unsigned ld(NXC_LDS_AS unsigned *a)
+    {
+        return __hip_atomic_load(a, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    NXC_DEV void publish(int w, unsigned count) const
+    {
+        __hip_atomic_store(hdr(w), count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// Why: a SIMD issues for its OLDEST wave first (tools/gpu_exp_var_trace.py, 1e6 packets: 4.5 / 7.0 /
+// 13.6 us per trip for the three waves of a SIMD; 3.4 for a wave alone).  The queue is empty after
+// 11-12 ms; the launch then ends with the 3 000-5 000-attempt chains, and those that sat in a slow
+// wave have made a third of the trips they would have made in a fast one.  The order of the queue
+// cannot put them first: longest first would end at 20-22 ms (tools/gpu_exp_var_order.py), but
+// the reference's controller only ever shrinks the stored step (Output.py:333-342), so a packet's
+// attempts follow from whether it survives its first returns to the surface -- 10 % of the long
+// chains misplaced and the gain is gone (same tool).  Plain (FAIR_ = false):
+// the highest throughput, for launches with dozens of packets per lane (1e7: 151 ms against 156).
+// Fair: 1e6 packets 33.0 -> 28.8-29.6 ms, 2e6 45.8 -> 42.8, 4e6 72.1 -> 69.5.
+template <bool FULL, bool FAIR_>     // FULL: gravity + radiation pressure + photo-loss known at compile time
+__global__ void __launch_bounds__(NXC_BLOCK_PERSIST)
 k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int64_t n,
       const double *__restrict__ soa0, const unsigned *__restrict__ order, double resolution, double outeredge, long long max_steps,
       double *__restrict__ final_out, double *__restrict__ hstore_out,
       DevCounters *__restrict__ ctr)
 {
+    constexpr bool FAIR = FAIR_ && NXC_VAR_FAIR;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nw = blockDim.x >> 6;                          // the host launches fewer waves for few packets
+    const VarMerge M{(int)((stage_bytes + 31) & ~31ll)};
+    if (FAIR && lane == 0) {                                 // before the staging barrier
+        M.hdr(wave)[0] = NXC_VAR_PENDING; M.hdr(wave)[1] = 0u; M.hdr(wave)[2] = 0u;
+        if (wave == 0)
+            for (int k = 4; k < 12; k++) M.hdr(0)[k] = 0u;
+    }
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, nullptr, &ctr->queue_head, n);
+    bool keeper = false, published = false;
+    int simd = 0, slot = 0, prev_live = -1, prio = 0;
+    if (FAIR) {
+        // HW_REG_HW_ID (4): WAVE_ID = bits 3:0 (the wave's slot on its SIMD), SIMD_ID = bits 5:4
+        const unsigned hw = __builtin_amdgcn_s_getreg((5 << 11) | (0 << 6) | 4);
+        slot = (int)(hw & 15u); simd = (int)(hw >> 4 & 3u);
+        unsigned r = 0;
+        if (lane == 0) r = __hip_atomic_fetch_add(M.hdr(0) + 8 + simd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        keeper = __builtin_amdgcn_readfirstlane(r) == 0;
+        if (keeper && lane == 0) M.publish(wave, 0u);
+    }
     const LutView T = lut_view(F.tab);
     const double resx = resolution, resv = 0.1 * resolution, resf = resolution;
     unsigned long long my_steps = 0, my_nonfinite = 0, my_bad = 0, my_neg = 0, my_unfinished = 0;
     WaveQueue q;
     q.start();
-    const int stage_off = (int)((stage_bytes + 31) & ~31ll) + (threadIdx.x >> 6) * NXC_WAVE_LDS_BYTES;
+    const int stage_off = M.wave0 + wave * NXC_WAVE_LDS_BYTES;
     bool has = false;
     long long id = -1, it = 0;
     unsigned my_trips = 0;
@@ -699,8 +765,96 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
         if (got >= 0) {
             id = got; it = 0; hs = 1000.0; has = true;
         }
-        if (__ballot(has) == 0) break;
+        if (FAIR && q.drained) {
+            const unsigned long long livem = __ballot(has);
+            int live = __popcll(livem);
+            if (!keeper) {
+                if (live > 0 && live <= NXC_VAR_MERGE_MAX) {
+                    int r = 0;
+                    if (lane < 4) r = __hip_atomic_load(M.room(lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long can = __ballot(lane < 4 && r >= live);
+                    if (can != 0) {
+                        // the keeper of the own SIMD if it can take them (that SIMD then loses a wave), else the first that can
+                        const int k = (can >> simd) & 1ull ? simd : (int)__builtin_ctzll(can);
+                        int old = 0;
+                        if (lane == 0) {
+                            old = __hip_atomic_fetch_sub(M.room(k), live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (old < live) __hip_atomic_fetch_add(M.room(k), live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        if (__builtin_amdgcn_readfirstlane(old) >= live) {
+                            if (has) {
+                                NXC_LDS_AS double *e = M.seg(wave) + __popcll(livem & ((1ull << lane) - 1ull));
+#pragma unroll
+                                for (int c = 0; c < 8; c++) e[c * NXC_VAR_MERGE_MAX] = s[c];
+                                e[8 * NXC_VAR_MERGE_MAX] = hs;
+                                e[9 * NXC_VAR_MERGE_MAX] = __longlong_as_double(it);
+                                e[10 * NXC_VAR_MERGE_MAX] = __longlong_as_double(id);
+                                has = false;
+                            }
+                            if (lane == 0) { M.hdr(wave)[1] = (unsigned)k; M.publish(wave, (unsigned)live); }
+                            published = true;
+                        }
+                    }
+                }
+            } else {
+                // room: what the lanes freed since the last look (all free lanes at the first)
+                const int freed = prev_live < 0 ? 64 - live : prev_live - live;
+                if (freed > 0 && lane == 0)
+                    __hip_atomic_fetch_add(M.room(simd), freed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // adopt what is addressed to this keeper: lane w looks at wave w's header
+                bool mine = false;
+                unsigned c = 0;
+                if (lane < nw) {
+                    c = M.ld(M.hdr(lane));
+                    mine = c != NXC_VAR_PENDING && c != 0u && M.hdr(lane)[1] == (unsigned)simd && M.hdr(lane)[2] == 0u;
+                }
+                unsigned long long offer = __ballot(mine);
+                while (offer != 0) {
+                    const int w = __builtin_ctzll(offer);
+                    offer &= offer - 1;
+                    const int got = __shfl((int)c, w, 64);       // reserved: fits
+                    const unsigned long long freem = __ballot(!has);
+                    const int rank = __popcll(freem & ((1ull << lane) - 1ull));
+                    if (!has && rank < got) {
+                        const NXC_LDS_AS double *e = M.seg(w) + rank;
+#pragma unroll
+                        for (int c2 = 0; c2 < 8; c2++) s[c2] = e[c2 * NXC_VAR_MERGE_MAX];
+                        hs = e[8 * NXC_VAR_MERGE_MAX];
+                        it = __double_as_longlong(e[9 * NXC_VAR_MERGE_MAX]);
+                        id = __double_as_longlong(e[10 * NXC_VAR_MERGE_MAX]);
+                        has = true;
+                    }
+                    if (lane == 0) M.hdr(w)[2] = 1u;
+                    live += got;
+                }
+                prev_live = live;
+            }
+        }
+        if (__ballot(has) == 0) {
+            if (!FAIR || !keeper) break;
+            // every wave has published, and nothing published to this keeper is left
+            bool open = false;
+            if (lane < nw) {
+                const unsigned c = M.ld(M.hdr(lane));
+                open = c == NXC_VAR_PENDING || (c != 0u && M.hdr(lane)[1] == (unsigned)simd && M.hdr(lane)[2] == 0u);
+            }
+            if (__ballot(open) == 0) break;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
         my_trips++;
+        if (FAIR && (my_trips & 3u) == 0) {
+            // every wave of the SIMD leads for a slice of the clock in turn (looked up every fourth
+            // trip: a slice lasts six)
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            const int pr = (int)(((t >> NXC_VAR_PRIO_SHIFT) + (unsigned long long)slot) % 3ull);
+            if (pr != prio) {
+                prio = pr;
+                if (pr == 2) __builtin_amdgcn_s_setprio(2);
+                else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         if (has) {
             bool done = !(s[0] > resolution && s[7] > 0.0);
             if (!done && it >= max_steps) { my_unfinished++; done = true; }
@@ -758,6 +912,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             }
         }
     }
+    if (FAIR && !keeper && !published && lane == 0) M.publish(wave, 0u);
 #ifdef NXC_VAR_TRACE
     if ((threadIdx.x & 63) == 0) {
         // HW_REG_HW_ID (4): SIMD_ID = bits 5:4, WAVE_ID = bits 3:0

@@ -222,12 +222,12 @@ def test_image_kernel_on_float32_samples_equals_the_restored_path(ctx, quantity)
     np.testing.assert_allclose(img32, img64, rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize('variant', ['by size', 'full', 'lean'])
+@pytest.mark.parametrize('variant', ['by size', 'fair', 'plain'])
 def test_variable_driver_bit_exact(ctx, coracle, variant, monkeypatch):
-    """k_var is launched as 768-thread workgroups (three waves per SIMD: many packets per lane) or
-    as 256-thread ones (two per SIMD: few -- the launch is then as long as its longest chains, which
-    run faster that way).  The library picks by size; NXC_TEST_VAR_VARIANT forces either: the same
-    bits whichever runs."""
+    """k_var has two launch forms of one arithmetic: with clock-rotated wave priorities and a merged
+    tail (the live packets of sparse waves handed to one keeper wave per SIMD through LDS) when the
+    launch is mostly tail, plain when every lane has dozens of packets.  The library picks by
+    size; NXC_TEST_VAR_VARIANT forces one: the same bits whichever runs."""
     if variant != 'by size':
         monkeypatch.setenv('NXC_TEST_VAR_VARIANT', variant)
     f = H.mercury_forces('Na', 1.3)

@@ -26,7 +26,7 @@ att = np.array(att)
 print('attempts of the first packets, each alone: max %d median %d mean %.0f' % (att.max(), np.median(att), att.mean()), flush=True)
 longest = int(np.argmax(att))
 top = np.argsort(-att)
-for variant in ('full', 'lean'):
+for variant in ('plain', 'fair'):
     os.environ['NXC_TEST_VAR_VARIANT'] = variant
     for K, label in ((1, 'the longest alone'), (64, 'copies of it: one full wave'), (64*4, '4 waves'),
                      (64*16, '16 waves'), (64*64, '64 waves'), (64*256, '256 waves'), (64*512, '512 waves'),

@@ -22,7 +22,7 @@ def run(cols, label):
         fin, att = ctx.integrate_var(res, edge); ms.append(ctx.last_kernel_ms())
     print('%-45s %7.2f ms' % (label, min(ms[1:])), flush=True)
     return att
-for variant in ('full', 'lean'):
+for variant in ('plain', 'fair'):
     os.environ['NXC_TEST_VAR_VARIANT'] = variant
     os.environ.pop('NXC_TEST_VAR_NO_ORDER', None)
     att = run(soa, variant + ': the product (flight key)')
