@@ -730,7 +730,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             for (int k = 4; k < 12; k++) M.hdr(0)[k] = 0u;
     }
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, nullptr, &ctr->queue_head, n);
-    bool keeper = false, published = false;
+    bool keeper = false, published = false, settled = false;
     int simd = 0, slot = 0, prev_live = -1, prio = 0;
     if (FAIR) {
         // HW_REG_HW_ID (4): WAVE_ID = bits 3:0 (the wave's slot on its SIMD), SIMD_ID = bits 5:4
@@ -765,7 +765,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
         if (got >= 0) {
             id = got; it = 0; hs = 1000.0; has = true;
         }
-        if (FAIR && q.drained) {
+        if (FAIR && q.drained && !settled) {
             const unsigned long long livem = __ballot(has);
             int live = __popcll(livem);
             if (!keeper) {
@@ -809,6 +809,12 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
                     mine = c != NXC_VAR_PENDING && c != 0u && M.hdr(lane)[1] == (unsigned)simd && M.hdr(lane)[2] == 0u;
                 }
                 unsigned long long offer = __ballot(mine);
+                // every wave has published and nothing is addressed to this keeper: it is on its
+                // own from here (no more looks, no more turns at the priority)
+                if (offer == 0 && __ballot(lane < nw && c == NXC_VAR_PENDING) == 0) {
+                    settled = true;
+                    __builtin_amdgcn_s_setprio(0);
+                }
                 while (offer != 0) {
                     const int w = __builtin_ctzll(offer);
                     offer &= offer - 1;
@@ -831,7 +837,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             }
         }
         if (__ballot(has) == 0) {
-            if (!FAIR || !keeper) break;
+            if (!FAIR || !keeper || settled) break;
             // every wave has published, and nothing published to this keeper is left
             bool open = false;
             if (lane < nw) {
@@ -843,7 +849,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             continue;
         }
         my_trips++;
-        if (FAIR && (my_trips & 3u) == 0) {
+        if (FAIR && !settled && (my_trips & 3u) == 0) {
             // every wave of the SIMD leads for a slice of the clock in turn (looked up every fourth
             // trip: a slice lasts six)
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
