@@ -246,6 +246,28 @@ def test_variable_driver_bit_exact(ctx, coracle, variant, monkeypatch):
     assert ctr['bad_step'] == ctr['nonfinite'] == ctr['neg_frac'] == ctr['unfinished'] == 0
 
 
+@pytest.mark.parametrize('variant', ['fair', 'plain'])
+def test_variable_driver_attempt_cap_travels_with_the_packet(ctx, coracle, variant, monkeypatch):
+    """max_steps ends a packet after that many attempts, wherever they were made: in the fair form
+    a packet's attempt count moves with it when a sparse wave hands it to its SIMD's keeper.  4e4
+    packets, a cap that a third of them reach: states, stored steps and total work as the C
+    oracle's, `unfinished` = the packets still alive at the cap."""
+    monkeypatch.setenv('NXC_TEST_VAR_VARIANT', variant)
+    f = H.mercury_forces('Na', 1.3)
+    H.set_ctx_forces(ctx, f)
+    n, endtime, cap = 40_000, 30000.0, 400
+    X0 = H.sample_x0(n, 99, endtime)
+    X0[:, 0] = np.random.default_rng(3).random(n)*endtime
+    ctx.upload_packets(X0)
+    g_final, g_hs = ctx.integrate_var(1e-4, 25.0, max_steps=cap)
+    ctr = ctx.counters()
+    c_final, c_hs, work, bad = coracle.integrate_var(f, X0, 1e-4, 25.0, max_steps=cap)
+    assert ctr['particle_steps'] == work and work > 5e6
+    assert np.array_equal(g_final, c_final) and np.array_equal(g_hs, c_hs)
+    capped = int(((c_final[:, 0] > 1e-4) & (c_final[:, 7] > 0)).sum())     # still flying at the cap
+    assert ctr['unfinished'] == capped and n//10 < capped < n
+
+
 def test_rccl_single_rank_allreduce(ctx, coracle):
     """The RCCL path (dlopen librccl, communicator, fp64 + u64 all-reduce on the handle's stream)
     with a world of one: the image pair must come back unchanged."""
