@@ -731,11 +731,13 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
     }
     stage_tables_and_args(blob, stage_bytes, soa0, order, final_out, nullptr, &ctr->queue_head, n);
     bool keeper = false, published = false, settled = false;
-    int simd = 0, slot = 0, prev_live = -1, prio = 0;
+    int prev_live = -1, prio = 0;
+    // HW_REG_HW_ID (4): WAVE_ID = bits 3:0 (the wave's slot on its SIMD), SIMD_ID = bits 5:4 -- read
+    // where needed (a wave stays where it is; two registers less to carry through the step)
+    auto hw_simd = []() { return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4); };
+    auto hw_slot = []() { return (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4); };
     if (FAIR) {
-        // HW_REG_HW_ID (4): WAVE_ID = bits 3:0 (the wave's slot on its SIMD), SIMD_ID = bits 5:4
-        const unsigned hw = __builtin_amdgcn_s_getreg((5 << 11) | (0 << 6) | 4);
-        slot = (int)(hw & 15u); simd = (int)(hw >> 4 & 3u);
+        const int simd = hw_simd();
         unsigned r = 0;
         if (lane == 0) r = __hip_atomic_fetch_add(M.hdr(0) + 8 + simd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         keeper = __builtin_amdgcn_readfirstlane(r) == 0;
@@ -766,6 +768,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             id = got; it = 0; hs = 1000.0; has = true;
         }
         if (FAIR && q.drained && !settled) {
+            const int simd = hw_simd();
             const unsigned long long livem = __ballot(has);
             int live = __popcll(livem);
             if (!keeper) {
@@ -839,6 +842,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
         if (__ballot(has) == 0) {
             if (!FAIR || !keeper || settled) break;
             // every wave has published, and nothing published to this keeper is left
+            const int simd = hw_simd();
             bool open = false;
             if (lane < nw) {
                 const unsigned c = M.ld(M.hdr(lane));
@@ -853,7 +857,7 @@ k_var(ForceK F, const unsigned char *__restrict__ blob, int64_t stage_bytes, int
             // every wave of the SIMD leads for a slice of the clock in turn (looked up every fourth
             // trip: a slice lasts six)
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-            const int pr = (int)(((t >> NXC_VAR_PRIO_SHIFT) + (unsigned long long)slot) % 3ull);
+            const int pr = (int)(((t >> NXC_VAR_PRIO_SHIFT) + (unsigned long long)hw_slot()) % 3ull);
             if (pr != prio) {
                 prio = pr;
                 if (pr == 2) __builtin_amdgcn_s_setprio(2);
