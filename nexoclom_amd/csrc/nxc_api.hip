@@ -2572,6 +2572,9 @@ int nxc_integrate_var(nxc_handle *h, double resolution, double outeredge, int64_
         int rc2;
         if ((rc2 = prep_kernel(kernel, lds))) return rc2;
         if ((rc2 = persistent_grid(h, kernel, &block, lds, n, &grid))) return rc2;
+#ifdef NXC_VAR_ONE_WG_PER_CU          /* experiment: with -DNXC_BLOCK_PERSIST_N=512, two waves per SIMD */
+        if (grid > h->n_cu) grid = h->n_cu;
+#endif
         if ((rc2 = begin_timed(h))) return rc2;
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, h->stream, h->F, h->d_blob,
                            (int64_t)h->force_bytes, n, h->have_order ? h->d_queue : h->d_packets,
